@@ -1,0 +1,113 @@
+"""ctypes binding of libasrk.so (the C ABI declared in include/asrk.h).
+
+The library is built in-tree by ``asr_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There is
+no fallback: if the shared object is missing or an entry point fails, the product raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasrk.so")
+
+ASRK_F32, ASRK_BF16 = 0, 1
+
+
+class AsrkError(RuntimeError):
+    pass
+
+
+class EncoderDims(Structure):
+    _fields_ = [("d_model", c_int), ("n_layers", c_int), ("n_heads", c_int), ("ffn_dim", c_int), ("n_mels", c_int)]
+
+
+class EncoderLayerWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "q_w", "q_b", "k_w", "v_w", "v_b", "o_w", "o_b", "ln1_w", "ln1_b",
+        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ln2_w", "ln2_b")]
+
+
+class EncoderWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "pos", "ln_w", "ln_b")] + [
+        ("layers", POINTER(EncoderLayerWeights))]
+
+
+class ProjectorDims(Structure):
+    _fields_ = [("audio_dim", c_int), ("text_dim", c_int)]
+
+
+class ProjectorParams(Structure):
+    _fields_ = [(n, c_void_p) for n in ("gamma", "w1", "b1", "w2", "b2")]
+
+
+class ProjectorGrads(Structure):
+    _fields_ = [(n, c_void_p) for n in ("gamma", "w1", "b1", "w2", "b2")]
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "asrk_version": (c_int, []),
+    "asrk_strerror": (c_char_p, [c_int]),
+    "asrk_logmel_plan_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "asrk_logmel_plan_destroy": (None, [c_void_p]),
+    "asrk_logmel_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "asrk_encoder_create": (c_int, [POINTER(EncoderDims), POINTER(EncoderWeights), c_void_p, POINTER(c_void_p)]),
+    "asrk_encoder_destroy": (None, [c_void_p]),
+    "asrk_encoder_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "asrk_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "asrk_projector_workspace_bytes": (c_size_t, [POINTER(ProjectorDims), c_int]),
+    "asrk_projector_saved_bytes": (c_size_t, [POINTER(ProjectorDims), c_int]),
+    "asrk_projector_forward": (c_int, [POINTER(ProjectorDims), POINTER(ProjectorParams), c_void_p, c_int, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "asrk_projector_backward": (c_int, [POINTER(ProjectorDims), POINTER(ProjectorParams), c_void_p, c_int, c_int,
+                                        c_void_p, POINTER(ProjectorGrads), c_void_p, c_void_p, c_void_p, c_size_t,
+                                        c_void_p]),
+    "asrk_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                               c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "asrk_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "asrk_attention_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libasrk.so once; raise (never fall back) if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsrkError(
+            f"{LIB_PATH} not found: build it with `make -C asr_amd/csrc` (or __graft_entry__.build()). "
+            "asr_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.asrk_version() < 100:
+        raise AsrkError("libasrk.so is older than this Python package")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "asrk") -> None:
+    if code != 0:
+        msg = load().asrk_strerror(code).decode()
+        raise AsrkError(f"{what} failed: {msg} (code {code})")
+
+
+def ptr(t) -> c_void_p:
+    """data_ptr of a torch tensor (or None) as c_void_p."""
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def current_stream():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

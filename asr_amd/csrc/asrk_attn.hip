@@ -1,0 +1,195 @@
+// Bidirectional multi-head attention forward, head_dim 64, flash-style (scores never leave the CU).
+//
+// Replaces HF WhisperAttention's attention_interface call for the encoder
+// (transformers/models/whisper/modeling_whisper.py:341-351 -> sdpa / :215-238 eager):
+// softmax(Q K^T) V with NO mask (the encoder passes None, :636-640) and scaling = 1.0 because q was
+// already multiplied by head_dim^-0.5 (:309; folded into the packed q weights).
+//
+// One workgroup = 4 waves = 128 query rows of one (clip, head); each wave owns 32 query rows.
+// K/V tiles of 64 keys stream through a double-buffered LDS ring with global_load_lds.
+// S^T = K Q^T is computed "swapped" (keys on MFMA rows, queries on the lanes), so a lane holds
+// the scores of ONE query: the row max/sum are in-lane reductions plus one exchange between the
+// two half-waves, and the exponentiated tile is already the B operand of O^T += V^T P^T
+// (accumulator-as-operand, no LDS round trip for P).  V^T fragments come from the row-major V
+// tile through ds_read_b64_tr_b16.  Softmax statistics and accumulators are fp32.
+#include "asrk_common.h"
+#include "asrk_gemm.h"
+
+namespace {
+
+constexpr int HD = 64;       // head_dim (Whisper: always 64)
+constexpr int QT = 128;      // query rows per workgroup
+constexpr int KT = 64;       // keys per tile
+constexpr int TILE_B = KT * HD * 2;  // 8 KiB
+
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
+    const short4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+    return __builtin_bit_cast(bf16x4, r);
+}
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;   // half-wave
+    const int l31 = lane & 31;
+    const int head = blockIdx.y, clip = blockIdx.z;
+    const int d = H * HD;
+    const int64_t ld = 3 * (int64_t)d;
+    const bf16_t* base = qkv + (int64_t)clip * T * ld + head * HD;
+    const int q0 = blockIdx.x * QT + wave * 32;
+
+    // ---- Q^T fragments (MFMA B operand): lane holds Q[q0 + l31][16 s + 8 hh + 0..7]
+    bf16x8 qf[4];
+    {
+        int qr = q0 + l31;
+        qr = qr < T ? qr : T - 1;
+        const bf16_t* qp = base + (int64_t)qr * ld + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+
+    // ---- staging: each thread moves 2 K chunks and 2 V chunks (16 B) per tile
+    const int srow = tid >> 3;  // + 32 * i
+    const int slot = tid & 7;
+    const int wave_lds = wave * 1024;
+    auto stage = [&](int kt, int buf) {
+        char* kb = smem + buf * (2 * TILE_B);
+        char* vb = kb + TILE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + 32 * i;
+            int kv = kt * KT + row;
+            kv = kv < T ? kv : T - 1;
+            const bf16_t* rp = base + (int64_t)kv * ld;
+            const int kc = slot ^ ((row >> 1) & 7);          // K image: chunk ^ ((row >> 1) & 7)
+            const int vc = slot ^ (((row >> 1) & 1) << 2);   // V image: chunk ^ (((row >> 1) & 1) << 2)
+            glds16(rp + d + kc * 8, kb + i * 4096 + wave_lds);
+            glds16(rp + 2 * d + vc * 8, vb + i * 4096 + wave_lds);
+        }
+    };
+
+    f32x16 o[2];
+    o[0] = f32x16{0.f};
+    o[1] = f32x16{0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // fragment read offsets
+    // K (A operand of S^T): row = 32 mt + l31, chunk = 2 s + hh, image swizzle (row >> 1) & 7
+    const int k_row_off = l31 * 128;
+    const int k_sw = (l31 >> 1) & 7;
+    // V^T (A operand of PV) through the transposing read: group g = (lane >> 4) & 1, i = lane & 15
+    const int vi = lane & 15, vg = (lane >> 4) & 1;
+
+    const int nkt = (T + KT - 1) / KT;
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        const char* kb = smem + (kt & 1) * (2 * TILE_B);
+        const char* vb = kb + TILE_B;
+
+        // ---- S^T[mt] = K[32 mt .. +31][:] . Q^T   (keys on rows/registers, queries on lanes)
+        f32x16 sacc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[mt][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + mt * 4096 + k_row_off + (((2 * s + hh) ^ k_sw) << 4));
+                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[mt], 0, 0, 0);
+            }
+        }
+        if (kt == nkt - 1 && (T % KT) != 0) {  // mask keys past the end of the clip
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kt * KT + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (kv >= T) sacc[mt][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax for this lane's query
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * LOG2E);
+        const float mb = m_new * LOG2E;
+        float psum = 0.f;
+        bf16x8 pf[2][2];  // [mt][k-step s]: registers 8 s .. 8 s + 7
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(fmaf(sacc[mt][r], LOG2E, -mb));
+                psum += p;
+                pf[mt][r >> 3][r & 7] = (bf16_t)p;
+            }
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+        // ---- O^T[ht] += V^T[32 ht ..][keys] . P^T   (k order inside a step: 8 (j >> 2) + 4 hh + (j & 3))
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht) {
+                    bf16x8 vf;
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+                        const int row = 32 * mt + 16 * s + 4 * hh + 8 * rd + (vi >> 2);
+                        const int chunk = 4 * ht + 2 * vg + ((vi & 3) >> 1);
+                        const int off = row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) + (vi & 1) * 8;
+                        const bf16x4 t = lds_read_tr16(vb + off);
+                        vf[4 * rd + 0] = t[0]; vf[4 * rd + 1] = t[1]; vf[4 * rd + 2] = t[2]; vf[4 * rd + 3] = t[3];
+                    }
+                    o[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[mt][s], o[ht], 0, 0, 0);
+                }
+    }
+
+    // ---- normalise and store: lane holds O[q][32 ht + (r & 3) + 8 (r >> 2) + 4 hh]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < T) {
+        bf16_t* op = out + ((int64_t)clip * T + q) * d + head * HD + 4 * hh;
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(o[ht][4 * g + j] * inv);
+                *reinterpret_cast<bf16x4*>(op + 32 * ht + 8 * g) = v;
+            }
+    }
+}
+
+}  // namespace
+
+int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, hipStream_t st) {
+    if (!qkv || !out) return ASRK_ERR_NULL;
+    if (B <= 0 || T <= 0 || H <= 0 || H > 65535 || B > 65535) return ASRK_ERR_SHAPE;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ASRK_ERR_ALIGN;
+    const size_t lds = 4 * TILE_B;
+    hipLaunchKernelGGL(attention_kernel, dim3((T + QT - 1) / QT, H, B), dim3(256), lds, st, qkv, out, T, H);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+extern "C" int asrk_attention_bf16(const void* qkv, void* out, int B, int T, int H, void* stream) {
+    return asrk_launch_attention((const bf16_t*)qkv, (bf16_t*)out, B, T, H, (hipStream_t)stream);
+}

@@ -1,0 +1,149 @@
+// Memory-bound row kernels: LayerNorm, RMSNorm, casts, layout changes.  One wave per row, 16-byte
+// accesses, fp32 statistics (two-pass in registers: mean, then centred variance).
+#include "asrk_common.h"
+#include "asrk_gemm.h"
+
+namespace {
+
+constexpr int MAX_V4 = 8;  // per-lane float4 chunks: D <= 64 * 4 * 8 = 2048
+
+// LayerNorm(x) * w + b, eps inside the sqrt (torch.nn.LayerNorm; HF modeling_whisper.py:392,402,642)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, void* __restrict__ out, int M,
+                                                        int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;  // float4 per row
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4 v[MAX_V4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = xr[c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[c];
+            const float4 bb = reinterpret_cast<const float4*>(b)[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            if (OUT_BF16) {
+                bf16x4 p;
+                p[0] = (bf16_t)o.x; p[1] = (bf16_t)o.y; p[2] = (bf16_t)o.z; p[3] = (bf16_t)o.w;
+                reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D)[c] = p;
+            } else {
+                reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D)[c] = o;
+            }
+        }
+    }
+}
+
+// LlamaRMSNorm (HF models/llama/modeling_llama.py:62-67): x * rsqrt(mean(x^2) + eps) in fp32, then
+// gamma * (.) ; emitted as the bf16 operand of linear_1.  rstd is kept for the backward.
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      bf16_t* __restrict__ xn, float* __restrict__ rstd_out, int M,
+                                                      int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4 v[MAX_V4];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = xr[c];
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+            bf16x4 p;
+            p[0] = (bf16_t)(g.x * (v[i].x * rstd));
+            p[1] = (bf16_t)(g.y * (v[i].y * rstd));
+            p[2] = (bf16_t)(g.z * (v[i].z * rstd));
+            p[3] = (bf16_t)(g.w * (v[i].w * rstd));
+            reinterpret_cast<bf16x4*>(xn + (size_t)row * D)[c] = p;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                            size_t n4, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        bf16x4 p;
+        p[0] = (bf16_t)(v.x * scale); p[1] = (bf16_t)(v.y * scale);
+        p[2] = (bf16_t)(v.z * scale); p[3] = (bf16_t)(v.w * scale);
+        reinterpret_cast<bf16x4*>(dst)[i] = p;
+    }
+}
+
+}  // namespace
+
+int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* out, bool out_bf16, int M, int D,
+                          float eps, hipStream_t st) {
+    if (!x || !w || !b || !out) return ASRK_ERR_NULL;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAX_V4) return ASRK_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)b & 15) || ((uintptr_t)out & 15)) return ASRK_ERR_ALIGN;
+    const dim3 grid((M + 3) / 4);
+    if (out_bf16)
+        hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, w, b, out, M, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, w, b, out, M, D, eps);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+int asrk_launch_rmsnorm_bf16(const float* x, const float* gamma, bf16_t* xn, float* rstd, int M, int D, float eps,
+                             hipStream_t st) {
+    if (!x || !gamma || !xn) return ASRK_ERR_NULL;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAX_V4) return ASRK_ERR_SHAPE;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, xn, rstd, M, D, eps);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+int asrk_launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, float scale, hipStream_t st) {
+    if (!src || !dst) return ASRK_ERR_NULL;
+    if (n & 3) return ASRK_ERR_SHAPE;
+    const size_t n4 = n >> 2;
+    if (n4 == 0) return ASRK_OK;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n4, scale);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+extern "C" int asrk_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, int M, int D,
+                              float eps, void* stream) {
+    if (out_dtype != ASRK_F32 && out_dtype != ASRK_BF16) return ASRK_ERR_UNSUPPORTED;
+    return asrk_launch_layernorm(x, w, b, out, out_dtype == ASRK_BF16, M, D, eps, (hipStream_t)stream);
+}

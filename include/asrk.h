@@ -1,0 +1,170 @@
+/*
+ * asrk.h - C ABI of libasrk.so: the MI355X (gfx950) audio hot path of alexkroman/asr.
+ *
+ *   log-mel front-end  ->  Whisper-style audio encoder (frozen, forward only)  ->  AudioProjector
+ *
+ * The reference is pure Python on torch / HF transformers and has no FFI of its own; each entry
+ * point below names the reference call it replaces (file:line, "HF:" = the third-party
+ * transformers package the reference calls).  asr_amd/ binds these with ctypes (see
+ * INTEGRATION.md for the stub a maintainer would add on the reference side).
+ *
+ * Conventions
+ *   - every pointer marked "dev" is device memory owned by the caller (a torch tensor's
+ *     data_ptr()); rows are contiguous; base addresses must be 16-byte aligned;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued asynchronously on it, the library never synchronises;
+ *   - return value 0 = ASRK_OK, negative = error (asrk_strerror); nothing throws or aborts;
+ *   - forward / backward entry points allocate nothing: scratch comes in through `ws`.
+ *     Only the *_create calls allocate (immutable tables / packed bf16 weights), once.
+ */
+#ifndef ASRK_H
+#define ASRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASRK_VERSION 100
+
+enum {
+    ASRK_OK = 0,
+    ASRK_ERR_NULL = -1,        /* required pointer is NULL */
+    ASRK_ERR_SHAPE = -2,       /* unsupported / inconsistent dimension */
+    ASRK_ERR_ALIGN = -3,       /* pointer not 16-byte aligned */
+    ASRK_ERR_HIP = -4,         /* HIP runtime call or kernel launch failed */
+    ASRK_ERR_WORKSPACE = -5,   /* workspace too small */
+    ASRK_ERR_UNSUPPORTED = -6, /* dtype / mode not implemented */
+    ASRK_ERR_LENGTH = -7       /* mel features are not 3000 frames long (HF modeling_whisper.py:612-616) */
+};
+
+enum { ASRK_F32 = 0, ASRK_BF16 = 1 };
+
+int asrk_version(void);
+const char* asrk_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Log-mel front-end.
+ * Replaces HF WhisperFeatureExtractor._torch_extract_fbank_features
+ * (HF:models/whisper/feature_extraction_whisper.py:135-168), which the reference reaches from
+ * src/train.py:54-59 (eval) and src/train.py:172-180 (collator).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct asrk_logmel_plan asrk_logmel_plan;
+
+/* mel_filters: HOST pointer, float32 [201][n_mels] row-major = HF's `self.mel_filters`
+ * (feature_extraction_whisper.py:95-103) cast to float32 (:156).  Builds the per-device constant
+ * tables (Hann window, twiddles, sparse mel rows) on the current device. */
+int asrk_logmel_plan_create(int n_mels, const float* mel_filters, asrk_logmel_plan** plan);
+void asrk_logmel_plan_destroy(asrk_logmel_plan* plan);
+
+/* wave  dev f32 [B][n_samples]   (already padded/truncated, :300-307; n_samples > 200)
+ * out   dev f32 [B][n_mels][n_samples/160]
+ * clip_max_ws dev f32 [B] scratch for the per-clip maximum (:160-162).
+ * STFT is Hann-400 / hop-160 / center + reflect pad; the last STFT frame is dropped (:154). */
+int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples,
+                    float* out, float* clip_max_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Audio encoder forward.
+ * Replaces WhisperEncoder.forward (src/modeling.py:33-40) -> HF WhisperEncoder.forward
+ * (HF:models/whisper/modeling_whisper.py:592-646) and everything it calls (:215-413).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int d_model, n_layers, n_heads, ffn_dim, n_mels;
+} asrk_encoder_dims;
+
+/* fp32 device pointers in the HF state-dict layouts (Linear weight = [out][in]). */
+typedef struct {
+    const float *q_w, *q_b, *k_w, *v_w, *v_b, *o_w, *o_b; /* self_attn.{q,k,v,out}_proj; k has no bias (:279) */
+    const float *ln1_w, *ln1_b;                            /* self_attn_layer_norm */
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    const float *ln2_w, *ln2_b;                            /* final_layer_norm */
+} asrk_encoder_layer_weights;
+
+typedef struct {
+    const float *conv1_w, *conv1_b; /* [d][n_mels][3], [d]   (:566) */
+    const float *conv2_w, *conv2_b; /* [d][d][3], [d]        (:567) */
+    const float* pos;               /* embed_positions.weight [1500][d] (:569) */
+    const float *ln_w, *ln_b;       /* layer_norm (:573) */
+    const asrk_encoder_layer_weights* layers; /* HOST array [n_layers] */
+} asrk_encoder_weights;
+
+typedef struct asrk_encoder asrk_encoder;
+
+/* Packs the frozen weights into the bf16 layouts the kernels read (QKV fused, q pre-scaled by
+ * head_dim^-0.5 as :309 does, conv taps reordered).  Requires head_dim == 64, d_model % 128 == 0,
+ * ffn_dim % 128 == 0, n_mels % 8 == 0.  The fp32 sources may be freed once `stream` has drained. */
+int asrk_encoder_create(const asrk_encoder_dims* dims, const asrk_encoder_weights* w, void* stream,
+                        asrk_encoder** enc);
+void asrk_encoder_destroy(asrk_encoder* enc);
+size_t asrk_encoder_workspace_bytes(const asrk_encoder* enc, int B);
+
+/* feats dev f32 [B][n_mels][n_frames]; n_frames must be 3000 (ASRK_ERR_LENGTH otherwise, :612-616)
+ * out   dev f32 [B][1500][d_model]  = last_hidden_state (:642-646).
+ * The attention mask the reference passes is ignored by HF (:607-609), so it is not an argument. */
+int asrk_encoder_forward(const asrk_encoder* enc, const float* feats, int B, int n_frames, float* out,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AudioProjector forward / backward.
+ * Replaces AudioProjector.forward (src/modeling.py:77-84: LlamaRMSNorm(eps 1e-6) -> linear_1 ->
+ * exact GELU -> linear_2 -> *0.01) and the autograd backward of its five parameters; the cast at
+ * src/modeling.py:220,301 is folded in through `out_dtype`.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int audio_dim, text_dim;
+} asrk_projector_dims;
+
+typedef struct {
+    const float *gamma, *w1, *b1, *w2, *b2; /* dev fp32 master params: norm.weight, linear_{1,2}.{weight,bias} */
+} asrk_projector_params;
+
+typedef struct {
+    float *gamma, *w1, *b1, *w2, *b2; /* dev fp32, OVERWRITTEN with this call's gradients */
+} asrk_projector_grads;
+
+size_t asrk_projector_workspace_bytes(const asrk_projector_dims* dims, int M);
+size_t asrk_projector_saved_bytes(const asrk_projector_dims* dims, int M);
+
+/* x dev f32 [M][audio_dim]; out dev [M][text_dim] in out_dtype (ASRK_F32 | ASRK_BF16).
+ * saved: dev buffer of asrk_projector_saved_bytes() kept for backward, or NULL for inference. */
+int asrk_projector_forward(const asrk_projector_dims* dims, const asrk_projector_params* p, const float* x,
+                           int M, void* out, int out_dtype, void* saved, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* grad_out dev [M][text_dim] in grad_dtype; `saved` from the matching forward; x = that forward's
+ * input.  grad_x (dev f32 [M][audio_dim]) may be NULL: the reference's projector input is produced
+ * under no_grad (src/modeling.py:36), so it never needs it. */
+int asrk_projector_backward(const asrk_projector_dims* dims, const asrk_projector_params* p,
+                            const void* grad_out, int grad_dtype, int M, const void* saved,
+                            const asrk_projector_grads* grads, float* grad_x, const float* x, void* ws,
+                            size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks (exported so the parity tests can check each kernel on its own through the
+ * same ABI; the entry points above are compositions of these).
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[m][n] = epilogue( sum_k x[m][k] * w[n][k] ),  x bf16 [M][K] (ldx), w bf16 [N][K] (K%64==0),
+ * epilogue: (+bias[n]) -> (gelu) -> (*alpha) -> (+res[(m % res_rows)][n], f32, ldr) -> out_dtype.
+ * HF: every nn.Linear on the path (modeling_whisper.py:279-282, 375-376; src/modeling.py:68-70). */
+int asrk_gemm_bf16(const void* x, int64_t ldx, const void* w, const float* bias, const float* res, int64_t ldr,
+                   int res_rows, void* out, int64_t ldo, int out_dtype, int M, int N, int K, int gelu,
+                   float alpha, void* stream);
+
+/* LayerNorm over the last dim (eps 1e-5, torch default; modeling_whisper.py:371,377,573):
+ * x f32 [M][D] -> out (ASRK_BF16 | ASRK_F32) [M][D]. */
+int asrk_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, int M, int D,
+                   float eps, void* stream);
+
+/* Bidirectional multi-head attention, head_dim 64, no mask, scaling 1.0 (q already scaled)
+ * (modeling_whisper.py:215-238, 341-351).  qkv bf16 [B*T][3*H*64] (q | k | v per row),
+ * out bf16 [B*T][H*64]. */
+int asrk_attention_bf16(const void* qkv, void* out, int B, int T, int H, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASRK_H */

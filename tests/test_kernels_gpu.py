@@ -1,0 +1,137 @@
+"""GPU parity of the building-block kernels, each called through the C ABI (ctypes) and compared
+with a plain fp32 torch computation of the same op on the same (bf16-rounded) operands."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from asr_amd import _lib
+
+    return _lib.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (1500, 768, 768), (300, 960, 768), (4500, 2304, 768),
+                                   (77, 132, 3072), (3000, 768, 256)])
+@pytest.mark.parametrize("mode", ["plain_bf16", "bias_gelu_bf16", "bias_res_f32", "alpha_f32"])
+def test_gemm(lib, M, N, K, mode):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    x = (torch.randn((M, K), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((N, K), device="cuda", generator=g) / np.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn((N,), device="cuda", generator=g)
+    res = torch.randn((M, N), device="cuda", generator=g)
+    ref = x.float() @ w.float().T
+    use_bias = mode != "plain_bf16"
+    gelu = mode == "bias_gelu_bf16"
+    use_res = mode == "bias_res_f32"
+    alpha = 0.01 if mode == "alpha_f32" else 1.0
+    out_bf16 = mode.endswith("bf16")
+    if use_bias:
+        ref = ref + bias
+    if gelu:
+        ref = _gelu(ref)
+    ref = ref * alpha
+    if use_res:
+        ref = ref + res
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    rc = lib.asrk_gemm_bf16(_p(x), K, _p(w), _p(bias if use_bias else None), _p(res if use_res else None), N, M, _p(out), N,
+                            1 if out_bf16 else 0, M, N, K, int(gelu), alpha, _stream())
+    assert rc == 0, lib.asrk_strerror(rc)
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    tol = (1e-2 if out_bf16 else 2e-5 * np.sqrt(K)) * max(scale, 1.0)
+    assert torch.isfinite(out.float()).all()
+    assert err <= tol, f"max err {err:.3e} vs tol {tol:.3e} (scale {scale:.2f})"
+
+
+def test_gemm_identity_asymmetric(lib):
+    """A = I against an asymmetric B catches a transposed / permuted accumulator map exactly."""
+    K = N = 128
+    M = 128
+    x = torch.eye(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.arange(N * K, device="cuda").reshape(N, K) % 251).float().sub(125.0).to(torch.bfloat16)  # exact in bf16
+    out = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    rc = lib.asrk_gemm_bf16(_p(x), K, _p(w), _p(None), _p(None), 0, 0, _p(out), N, 0, M, N, K, 0, 1.0, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, w.float().T)
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    x = torch.zeros((64, 96), device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros((64, 64), device="cuda")
+    assert lib.asrk_gemm_bf16(_p(x), 96, _p(x), _p(None), _p(None), 0, 0, _p(out), 64, 0, 64, 64, 96, 0, 1.0, _stream()) != 0
+    assert lib.asrk_gemm_bf16(_p(None), 64, _p(x), _p(None), _p(None), 0, 0, _p(out), 64, 0, 64, 64, 64, 0, 1.0, _stream()) != 0
+
+
+@pytest.mark.parametrize("M,D", [(1, 128), (1500, 768), (333, 1280), (64, 256)])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_layernorm(lib, M, D, out_bf16):
+    g = torch.Generator(device="cuda").manual_seed(M + D)
+    x = torch.randn((M, D), device="cuda", generator=g) * 3 + 1.5
+    w = torch.randn((D,), device="cuda", generator=g)
+    b = torch.randn((D,), device="cuda", generator=g)
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    out = torch.empty((M, D), device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    rc = lib.asrk_layernorm(_p(x), _p(w), _p(b), _p(out), int(out_bf16), M, D, 1e-5, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= (4e-2 if out_bf16 else 2e-5), err
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 128, 2), (1, 1500, 2), (2, 1500, 12), (1, 100, 3), (3, 257, 1)])
+def test_attention(lib, B, T, H):
+    d = 64 * H
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + T + H)
+    qkv = torch.randn((B * T, 3 * d), device="cuda", generator=g)
+    qkv[:, :d] *= 0.35  # q already carries the head_dim^-0.5 scaling
+    qkv = qkv.to(torch.bfloat16)
+    out = torch.full((B * T, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    rc = lib.asrk_attention_bf16(_p(qkv), _p(out), B, T, H, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    f = qkv.float().reshape(B, T, 3, H, 64)
+    q, k, v = f[:, :, 0].transpose(1, 2), f[:, :, 1].transpose(1, 2), f[:, :, 2].transpose(1, 2)
+    p = torch.softmax(q @ k.transpose(2, 3), dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B * T, d)
+    err = (out.float() - ref).abs().max().item()
+    assert torch.isfinite(out.float()).all()
+    assert err <= 2e-2, f"max err {err:.3e}"
+
+
+def test_attention_online_softmax_rescale(lib):
+    """Force the running-max rescale: one key, late in the sequence, dominates one query."""
+    B, T, H = 1, 320, 1
+    g = torch.Generator(device="cuda").manual_seed(9)
+    qkv = torch.randn((T, 192), device="cuda", generator=g) * 0.3
+    qkv[5, 0:64] = 2.0          # query 5
+    qkv[300, 64:128] = 4.0      # key 300 (5th tile) -> score 512 for query 5
+    qkv[10, 64:128] = 1.0       # an earlier, smaller spike in tile 0
+    qkv = qkv.to(torch.bfloat16)
+    out = torch.empty((T, 64), device="cuda", dtype=torch.bfloat16)
+    assert lib.asrk_attention_bf16(_p(qkv), _p(out), B, T, H, _stream()) == 0
+    torch.cuda.synchronize()
+    f = qkv.double()
+    p = torch.softmax(f[:, :64] @ f[:, 64:128].T, dim=-1)
+    ref = p @ f[:, 128:]
+    assert (out.double() - ref).abs().max().item() <= 2e-2
+    assert (out[5].double() - f[300, 128:]).abs().max().item() <= 2e-2  # query 5 attends to key 300 only

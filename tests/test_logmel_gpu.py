@@ -1,0 +1,111 @@
+"""GPU parity of the HIP log-mel front-end (through the C ABI) against the oracle and the HF
+golden fixtures.  Tolerance: 1e-4 absolute (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import logmel as oracle_logmel
+from tests import signals
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def extractors():
+    from asr_amd import LogMelFeatureExtractor
+
+    return {n: LogMelFeatureExtractor(feature_size=n) for n in (80, 128)}
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("case", list(signals.LOGMEL_CASES))
+def test_single_clip_matches_golden(extractors, golden_dir, n_mels, case):
+    g = np.load(f"{golden_dir}/logmel_{n_mels}.npz")
+    clip = signals.LOGMEL_CASES[case][0]()
+    r = extractors[n_mels](clip, sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
+    assert r.input_features.is_cuda and r.input_features.dtype == torch.float32
+    feats = r.input_features.cpu().numpy()
+    assert feats.shape == (1, n_mels, 3000)
+    ref = g[case + "__features"]
+    err = np.abs(feats[0] - ref).max()
+    assert err <= TOL, f"{case}/{n_mels}: max abs err {err:.3e}"
+    assert r.attention_mask.dtype == torch.int32
+    assert np.array_equal(r.attention_mask.cpu().numpy()[0], g[case + "__mask"])
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_collator_batch_matches_golden(extractors, golden_dir, n_mels):
+    g = np.load(f"{golden_dir}/logmel_{n_mels}.npz")
+    names = ["short3005", "speechlike12", "tiny250", "noise30"]
+    clips = [signals.LOGMEL_CASES[n][0]() for n in names]
+    r = extractors[n_mels](clips, sampling_rate=16000, return_tensors="pt", return_attention_mask=True,
+                           padding="max_length", max_length=480000)
+    feats = r["input_features"].cpu().numpy()
+    assert feats.shape == (4, n_mels, 3000)
+    assert np.array_equal(r["attention_mask"].cpu().numpy(), g["batch__mask"])
+    for i, n in enumerate(names):
+        assert np.abs(feats[i] - g[n + "__features"]).max() <= TOL, n
+    # per-clip max: a clip's features do not depend on its batch neighbours
+    alone = extractors[n_mels](clips[1], sampling_rate=16000, return_tensors="np").input_features
+    assert np.array_equal(alone[0], feats[1])
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_padding_longest(extractors, golden_dir, n_mels):
+    g = np.load(f"{golden_dir}/logmel_{n_mels}.npz")
+    clips = [signals.LOGMEL_CASES["short3005"][0](), signals.LOGMEL_CASES["tiny250"][0]()]
+    r = extractors[n_mels](clips, sampling_rate=16000, return_tensors="np", return_attention_mask=True,
+                           padding="longest")
+    assert r.input_features.shape == g["longest__features"].shape
+    assert np.abs(r.input_features - g["longest__features"]).max() <= TOL
+    assert np.array_equal(r.attention_mask, g["longest__mask"])
+
+
+def test_matches_oracle_on_random_batch(extractors):
+    rng = np.random.default_rng(5)
+    lens = [480000, 16000, 77777, 401, 239999]
+    clips = [np.clip(rng.standard_normal(n) * 0.2, -1, 1).astype(np.float32) for n in lens]
+    r = extractors[80](clips, sampling_rate=16000, return_tensors="np", return_attention_mask=True)
+    o = oracle_logmel.extract(clips, n_mels=80, sampling_rate=16000)
+    assert np.abs(r.input_features - o["input_features"]).max() <= TOL
+    assert np.array_equal(r.attention_mask, o["attention_mask"])
+
+
+def test_errors_and_edge_cases(extractors):
+    fe = extractors[80]
+    with pytest.raises(ValueError):
+        fe(np.zeros(1000, dtype=np.float32), sampling_rate=8000)
+    with pytest.raises(ValueError):
+        fe(np.zeros((2, 2, 100), dtype=np.float32), sampling_rate=16000)
+    # list of python floats, float64 array, truncation of > 30 s
+    r = fe([0.0] * 500, sampling_rate=16000, return_tensors="pt")
+    assert r.input_features.shape == (1, 80, 3000)
+    long_clip = np.ones(500000, dtype=np.float64) * 0.01
+    r = fe(long_clip, sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
+    assert r.input_features.shape == (1, 80, 3000) and int(r.attention_mask.sum()) == 3000
+    # device-resident input
+    w = torch.zeros((3, 480000), device="cuda")
+    f = fe.extract_from_device(w)
+    assert f.shape == (3, 80, 3000) and torch.all(f == -1.5)
+
+
+def test_full_size_properties(extractors):
+    """BASELINE config 2 size (256 x 30 s): properties that need no oracle run."""
+    fe = extractors[80]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = (torch.randn((256, 480000), device="cuda", generator=g) * 0.1).clamp_(-1, 1)
+    w[7, 100000:] = 0.0  # silence tail
+    f = fe.extract_from_device(w)
+    torch.cuda.synchronize()
+    assert torch.isfinite(f).all()
+    mx = f.amax(dim=(1, 2))
+    mn = f.amin(dim=(1, 2))
+    assert torch.all(mn >= mx - 2.0 - 1e-6)  # max-8 floor in log10 units == 2.0 after /4
+    assert torch.all(f[7, :, 700:] == f[7, 0, 2999])  # silence tail sits on the floor
+    # clip-in-batch == clip-alone, bit for bit
+    assert torch.equal(fe.extract_from_device(w[5:6].clone())[0], f[5])
+    # scaling the waveform by 2 shifts log-mel by log10(4)/4 where the floor is not active
+    f2 = fe.extract_from_device(w[:4] * 2.0)
+    d = (f2 - f[:4])
+    assert torch.allclose(d[:3], torch.full_like(d[:3], float(np.log10(4.0) / 4.0)), atol=2e-5)
