@@ -68,7 +68,18 @@ _SIGNATURES = {
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "asrk_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "asrk_attention_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "asrk_profile_enable": (c_int, [c_int]),
+    "asrk_profile_read": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_int]),
 }
+
+PROF_GEMM, PROF_ATTENTION, PROF_LOGMEL, PROF_NORM = 0, 1, 2, 3
+
+
+def profile_read(cat: int, reset: bool = True):
+    """(total_ms, total_work, launches) of one kernel category since the last reset (stream must be idle)."""
+    ms, work, n = ctypes.c_double(), ctypes.c_double(), c_int()
+    check(load().asrk_profile_read(cat, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n), int(reset)))
+    return ms.value, work.value, n.value
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

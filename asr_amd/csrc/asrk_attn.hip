@@ -14,6 +14,7 @@
 // tile through ds_read_b64_tr_b16.  Softmax statistics and accumulators are fp32.
 #include "asrk_common.h"
 #include "asrk_gemm.h"
+#include "asrk_prof.h"
 
 namespace {
 
@@ -186,6 +187,7 @@ int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, h
     if (B <= 0 || T <= 0 || H <= 0 || H > 65535 || B > 65535) return ASRK_ERR_SHAPE;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ASRK_ERR_ALIGN;
     const size_t lds = 4 * TILE_B;
+    AsrkProfScope prof(ASRK_PROF_ATTENTION, 4.0 * B * H * (double)T * T * HD, st);
     hipLaunchKernelGGL(attention_kernel, dim3((T + QT - 1) / QT, H, B), dim3(256), lds, st, qkv, out, T, H);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }

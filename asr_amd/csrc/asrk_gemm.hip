@@ -19,6 +19,7 @@
 // overlapping rows (x_rs = C for stride 1, 2C for stride 2).  The output has the same kind of map.
 #include "asrk_common.h"
 #include "asrk_gemm.h"
+#include "asrk_prof.h"
 
 namespace {
 
@@ -161,6 +162,7 @@ int launch(const GemmArgs& a, hipStream_t st) {
     auto kern = gemm_bf16_kernel<GELU, OUT_BF16>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ASRK_ERR_HIP;
+    AsrkProfScope prof(ASRK_PROF_GEMM, 2.0 * a.M * a.N * a.K, st);
     hipLaunchKernelGGL(kern, dim3(tiles, a.splits), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }

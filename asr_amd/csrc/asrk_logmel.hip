@@ -19,6 +19,7 @@
 // Kernel 2 (logmel_finish_kernel): applies max(x, clip_max - 8) and (x + 4) / 4 in place.
 #include "asrk_common.h"
 #include "asrk_fft400.h"
+#include "asrk_prof.h"
 
 namespace {
 
@@ -195,6 +196,8 @@ extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, 
     ASRK_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)TILE_LDS_BYTES));
     ASRK_CHECK_HIP(hipMemsetAsync(clip_max_ws, 0, (size_t)B * 4, st));
+    // algorithmic bytes: read the waveform once, write the features once
+    AsrkProfScope prof(ASRK_PROF_LOGMEL, (double)B * ((double)n_samples * 4 + (double)plan->n_mels * n_frames * 4), st);
     dim3 grid((n_frames + TILE_F - 1) / TILE_F, B);
     hipLaunchKernelGGL(logmel_tile_kernel, grid, dim3(NTHREADS), TILE_LDS_BYTES, st, wave, n_samples, n_frames,
                        plan->n_mels, plan->tables, out, reinterpret_cast<unsigned*>(clip_max_ws));

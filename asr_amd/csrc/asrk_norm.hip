@@ -2,6 +2,7 @@
 // accesses, fp32 statistics (two-pass in registers: mean, then centred variance).
 #include "asrk_common.h"
 #include "asrk_gemm.h"
+#include "asrk_prof.h"
 
 namespace {
 
@@ -116,6 +117,7 @@ int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* 
     if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAX_V4) return ASRK_ERR_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)b & 15) || ((uintptr_t)out & 15)) return ASRK_ERR_ALIGN;
     const dim3 grid((M + 3) / 4);
+    AsrkProfScope prof(ASRK_PROF_NORM, (double)M * D * (out_bf16 ? 6.0 : 8.0), st);
     if (out_bf16)
         hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, w, b, out, M, D, eps);
     else

@@ -1,0 +1,20 @@
+// Optional per-launch event timing (off by default; zero cost when off beyond one branch).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { ASRK_PROF_GEMM = 0, ASRK_PROF_ATTENTION = 1, ASRK_PROF_LOGMEL = 2, ASRK_PROF_NORM = 3 };
+
+bool asrk_prof_enabled();
+int asrk_prof_begin(int cat, double work, hipStream_t st);
+void asrk_prof_end(int id, hipStream_t st);
+
+struct AsrkProfScope {
+    int id;
+    hipStream_t st;
+    AsrkProfScope(int cat, double work, hipStream_t s) : id(-1), st(s) {
+        if (asrk_prof_enabled()) id = asrk_prof_begin(cat, work, s);
+    }
+    ~AsrkProfScope() {
+        if (id >= 0) asrk_prof_end(id, st);
+    }
+};

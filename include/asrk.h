@@ -164,6 +164,16 @@ int asrk_layernorm(const float* x, const float* w, const float* b, void* out, in
  * out bf16 [B*T][H*64]. */
 int asrk_attention_bf16(const void* qkv, void* out, int B, int T, int H, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hook (no counterpart in the reference, which has no profiler: SURVEY section 5).
+ * When enabled, every GEMM / attention / log-mel / LayerNorm launch is bracketed by HIP events on
+ * its own stream; asrk_profile_read sums one category (0 GEMM: work = 2MNK flops, 1 attention:
+ * 4*B*H*T*T*64 flops, 2 log-mel: algorithmic bytes, 3 LayerNorm: bytes) after the caller has
+ * synchronised.  bench.py uses it for the `roofline` object.  Off by default.
+ * ---------------------------------------------------------------------------------------- */
+int asrk_profile_enable(int on);
+int asrk_profile_read(int category, double* total_ms, double* total_work, int* launches, int reset);
+
 #ifdef __cplusplus
 }
 #endif
