@@ -27,6 +27,40 @@ struct GemmArgs {
 
 // out = (((acc + bias) -> gelu?) * alpha [* gelu'(pre)]) + res
 int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);
+int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);  // 256x256 tiles, splits == 1
+
+// Shared epilogue: v = 4 consecutive n (n .. n+3) of output row m.  `orow` is the element offset
+// of the output row, `rrow` the residual row (or null).
+template <bool GELU, bool OUT_BF16>
+__device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& a, f32x4 v, int m, int n, int64_t orow,
+                                                    const float* rrow) {
+    if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+    }
+    v *= a.alpha;
+    if (a.dg_pre) {
+        const bf16x4 pz = *reinterpret_cast<const bf16x4*>(a.dg_pre + (int64_t)m * a.ld_dg + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad((float)pz[j]);
+    }
+    if (rrow) {
+        const float4 rr = *reinterpret_cast<const float4*>(rrow + n);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    }
+    if (OUT_BF16) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + orow + n) = o;
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + n) = v;
+    }
+}
 
 // small helpers implemented in asrk_norm.hip
 int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* out, bool out_bf16, int M, int D,

@@ -21,6 +21,8 @@
 #include "asrk_gemm.h"
 #include "asrk_prof.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -124,33 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn * 64 + nt * 16 + fq * 4;
             if (n >= a.N) continue;
-            f32x4 v = acc[nt][mt];
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (GELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            }
-            v *= a.alpha;
-            if (a.dg_pre) {
-                const bf16x4 pz = *reinterpret_cast<const bf16x4*>(a.dg_pre + (int64_t)m * a.ld_dg + n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad((float)pz[j]);
-            }
-            if (rrow) {
-                const float4 rr = *reinterpret_cast<const float4*>(rrow + n);
-                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            }
-            if (OUT_BF16) {
-                bf16x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + orow + n) = o;
-            } else {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + n) = v;
-            }
+            gemm_epilogue_store<GELU, OUT_BF16>(a, acc[nt][mt], m, n, orow, rrow);
         }
     }
 }
@@ -180,6 +156,13 @@ int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st
         return ASRK_ERR_ALIGN;
     if ((a.x_bs % 8) || (a.x_rs % 8) || (a.o_bs % 4) || (a.o_rs % 4) || (a.o_off % 4) || (a.ldr % 4))
         return ASRK_ERR_ALIGN;
+    // Tile choice: 256 x 256 tiles (one workgroup per CU, deep prefetch) once there are enough of
+    // them to fill the chip several times over; 128 x 128 tiles otherwise.  ASRK_GEMM_TILE=128|256
+    // overrides (A/B measurements only).
+    static const int forced = [] { const char* e = getenv("ASRK_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const bool big = a.splits == 1 && (forced == 256 || (forced == 0 && tiles256 >= 512 && (a.N % 256) == 0));
+    if (big) return asrk_gemm256_launch(a, gelu, out_bf16, st);
     if (gelu) return out_bf16 ? launch<true, true>(a, st) : launch<true, false>(a, st);
     return out_bf16 ? launch<false, true>(a, st) : launch<false, false>(a, st);
 }
