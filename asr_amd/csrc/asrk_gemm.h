@@ -23,11 +23,32 @@ struct GemmArgs {
     // optional split-K: blockIdx.y = split s covers K tiles [s*kt_per_split, ...), writes out + s*o_split
     int splits;
     int64_t o_split;
+    int nsplit;  // set by the 256-tile launcher: n-groups of the XCD grid (1, 2, 4, 8)
 };
 
 // out = (((acc + bias) -> gelu?) * alpha [* gelu'(pre)]) + res
 int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);
 int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);  // 256x256 tiles, splits == 1
+
+// Element part of the epilogue (everything except residual and store) for 4 consecutive n of row m.
+template <bool GELU>
+__device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v, int m, int n) {
+    if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+    }
+    v *= a.alpha;
+    if (a.dg_pre) {
+        const bf16x4 pz = *reinterpret_cast<const bf16x4*>(a.dg_pre + (int64_t)m * a.ld_dg + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad((float)pz[j]);
+    }
+    return v;
+}
 
 // Shared epilogue: v = 4 consecutive n (n .. n+3) of output row m.  `orow` is the element offset
 // of the output row, `rrow` the residual row (or null).

@@ -1,64 +1,108 @@
 // Large-tile variant of the bf16 MFMA GEMM (same contract as asrk_gemm.hip) for the big
-// activations x weights products of the encoder: 256(m) x 256(n) x 64(k) tiles, 512 threads =
-// 8 waves as 2(m) x 4(n), each wave 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16
-// (128 accumulator registers).  One workgroup per CU (128 KiB LDS = 2 stages x (X 32 KiB + W 32 KiB)).
+// activations x weights products of the encoder: 256(m) x 256(n) tiles, 512 threads = 8 waves as
+// 2(m) x 4(n), each wave 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16 (128 accumulator
+// registers).  One workgroup per CU.
 //
-// Pipeline: global_load_lds prefetch runs TWO K tiles ahead and stays in flight across the
-// barriers: the loop uses raw s_barrier with counted s_waitcnt vmcnt(8) (never a draining
-// __syncthreads), so the HBM/L2 latency of tile t+1 hides under the 64 MFMAs per wave of tile t.
-//   top:    vmcnt(8) [my loads of tile t landed]  ; s_barrier  [everyone's landed]
-//   body:   24 ds_read_b128 + 64 MFMA per wave from stage t&1
-//   bottom: lgkmcnt(0) ; s_barrier [everyone done reading stage t&1] ; issue loads of tile t+2 into it
-// LDS image and swizzle are those of asrk_gemm.hip (linear per wave, chunk ^= row & 7 applied to
-// the source address and to the fragment read).
+// Pipeline: an NSTAGE-deep LDS ring of K slices (BK = 64 x 2 stages, or BK = 32 x 4/5 stages) filled
+// by global_load_lds; loads run NSTAGE-1 slices ahead and stay in flight across the barriers: the
+// loop uses ONE raw s_barrier per slice with a counted s_waitcnt vmcnt(N) (never a draining
+// __syncthreads), so HBM/L2 latency hides under the MFMAs of the slices in between.
+//   top of slice t:  vmcnt((NSTAGE-2) * G)  [my loads of slice t landed] ; s_barrier [everyone's landed,
+//                    and everyone has finished reading slice t-1]
+//                    issue loads of slice t+NSTAGE-1 into the ring slot slice t-1 just vacated
+//                    ds_read_b128 fragments + MFMAs of slice t
+// LDS image: linear per wave (hardware constraint of LDS-DMA); the XOR bank swizzle is applied to the
+// per-lane SOURCE address and again on the fragment read (128-B rows: chunk ^= row & 7; 64-B rows:
+// chunk ^= ((row >> 3) & 1) << 1; both conflict-free for ds_read_b128, checked with
+// SQ_LDS_BANK_CONFLICT = 0).
+// Epilogue: accumulators go through LDS so that every global store / residual load covers whole
+// rows (16 B per lane, 1 KiB per wave-instruction).
 #include "asrk_common.h"
 #include "asrk_gemm.h"
 #include "asrk_prof.h"
 
+#include <cstdlib>
+
+#ifdef ASRK_STAMPS
+// Diagnostic build only (tools/build_diag.sh): per-workgroup s_memtime stamps, never in the product.
+__device__ unsigned long long g_stamps[16384 * 8];
+extern "C" int asrk_debug_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define STAMP(i) do { if (tid == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int OPER_BYTES = BM * BK * 2;      // 32 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * OPER_BYTES;  // 64 KiB
+constexpr int BM = 256;
 
-template <bool GELU, bool OUT_BF16>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][X tile | W tile]
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// WN = waves along n (4: 256 x 256 tile, 512 threads, 1 workgroup / CU;  2: 256 x 128 tile, 256 threads,
+// 2 workgroups / CU so that one's epilogue overlaps the other's K loop).
+template <int WN, int BK, int NSTAGE, bool GELU, bool OUT_BF16>
+__global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) {
+    constexpr int NTHR = 128 * WN, NW = 2 * WN, BN = 64 * WN;
+    constexpr int RB = BK * 2;              // bytes per LDS row
+    constexpr int CPR = RB / 16;            // 16-byte chunks per row (8 or 4)
+    constexpr int XOPER = 256 * RB;         // bytes of the X slice per stage
+    constexpr int STAGE = XOPER + BN * RB;
+    constexpr int GX = 256 * CPR / NTHR, GW = BN * CPR / NTHR;  // global_load_lds per thread per stage
+    constexpr int G = GX + GW;
+    constexpr int RPR = NTHR / CPR;         // rows staged per round of NTHR lanes
+    constexpr int KS = BK / 32;             // MFMA k-steps per stage
+    constexpr int EP_ROW_BF16 = BN * 2 + 16;  // epilogue staging row strides (bytes)
+    constexpr int EP_ROW_F32 = BN * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSTAGE][X slice | W slice]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
 
-    const int tiles_n = (a.N + BN - 1) / BN;
-    const int nblk = gridDim.x;
-    const int q = nblk >> 3, r = nblk & 7;
+    // ---- tile -> workgroup map.  Blocks b and b+8 share an XCD (and its 4 MiB L2).  The 8 XCDs
+    //      form an (8/nsplit) x nsplit grid over (m, n): an XCD owns a contiguous run of m panels
+    //      and 1/nsplit of the n tiles, walked n-fastest.
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const int ns = a.nsplit, mgc = 8 / ns;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int m0 = (lin / tiles_n) * BM;
-    const int n0 = (lin % tiles_n) * BN;
+    const int tn_per = tiles_n / ns, tm_per = (tiles_m + mgc - 1) / mgc;
+    const int tm = (xcd / ns) * tm_per + idx / tn_per;
+    if (idx / tn_per >= tm_per || tm >= tiles_m) return;  // padding blocks of the XCD grid
+    const int m0 = tm * BM;
+    const int n0 = ((xcd % ns) * tn_per + idx % tn_per) * BN;
 
-    const int srow = tid >> 3;                 // + 64 * i
-    const int chunk = (tid & 7) ^ (srow & 7);  // source-side swizzle
-    const bf16_t* xp[4];
-    const bf16_t* wp[4];
+    // ---- per-thread staging sources (CPR/2 rows of X and of W per stage)
+    const int srow = tid / CPR;  // + RPR * i   (RPR is a multiple of 16, so the swizzle term is the same for all i)
+    const int sswz = CPR == 8 ? (srow & 7) : (((srow >> 3) & 1) << 1);
+    const int chunk = (tid % CPR) ^ sswz;
+    const bf16_t* xp[GX];
+    const bf16_t* wp[GW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + srow + 64 * i;
+    for (int i = 0; i < GX; ++i) {
+        int m = m0 + srow + RPR * i;
         m = m < a.M ? m : a.M - 1;
         xp[i] = a.X + (int64_t)(m / a.x_rpb) * a.x_bs + (int64_t)(m % a.x_rpb) * a.x_rs + chunk * 8;
-        int n = n0 + srow + 64 * i;
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        int n = n0 + srow + RPR * i;
         n = n < a.N ? n : a.N - 1;
         wp[i] = a.W + (int64_t)n * a.K + chunk * 8;
     }
     const int wave_lds = wave * 1024;
 
-    auto stage = [&](int kt, char* sb) {
+    auto stage = [&](int kt, int slot) {
+        char* sb = smem + slot * STAGE;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(xp[i] + k0, sb + i * 8192 + wave_lds);
-            glds16(wp[i] + k0, sb + OPER_BYTES + i * 8192 + wave_lds);
-        }
+        for (int i = 0; i < GX; ++i) glds16(xp[i] + k0, sb + i * (NTHR * 16) + wave_lds);
+#pragma unroll
+        for (int i = 0; i < GW; ++i) glds16(wp[i] + k0, sb + XOPER + i * (NTHR * 16) + wave_lds);
     };
 
     f32x4 acc[4][8];  // [nt][mt]
@@ -69,23 +113,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 
     const int frow = lane & 15;
     const int fq = lane >> 4;
-    const int sw = lane & 7;
-    const int x_off = (wm * 128 + frow) * 128;
-    const int w_off = OPER_BYTES + (wn * 64 + frow) * 128;
+    const int fswz = CPR == 8 ? (frow & 7) : (((frow >> 3) & 1) << 1);
+    const int x_off = (wm * 128 + frow) * RB;
+    const int w_off = XOPER + (wn * 64 + frow) * RB;
 
     auto compute = [&](const char* sb) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fq) ^ sw) << 4;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ fswz) << 4;
             bf16x8 wf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(sb + w_off + t * 2048 + coff);
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(sb + w_off + t * 16 * RB + coff);
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh) {
                 bf16x8 xf[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    xf[t] = *reinterpret_cast<const bf16x8*>(sb + x_off + (mh * 4 + t) * 2048 + coff);
+                    xf[t] = *reinterpret_cast<const bf16x8*>(sb + x_off + (mh * 4 + t) * 16 * RB + coff);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -97,59 +141,147 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     };
 
     const int nkt = a.K / BK;
-    char* const s0 = smem;
-    char* const s1 = smem + STAGE_BYTES;
-    stage(0, s0);
-    if (nkt > 1) stage(1, s1);
-    for (int kt = 0; kt < nkt; kt += 2) {
-        // ---- even tile from stage 0
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        compute(s0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 2 < nkt) stage(kt + 2, s0);
-        if (kt + 1 >= nkt) break;
-        // ---- odd tile from stage 1
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        compute(s1);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 3 < nkt) stage(kt + 3, s1);
+    STAMP(0);
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nkt) stage(s, s);
+    int slot = 0, fill = NSTAGE - 1;  // ring slot of slice t / of slice t + NSTAGE - 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int ahead = nkt - 1 - kt;  // slices after this one whose loads are already issued (capped below)
+        if (ahead >= NSTAGE - 2) wait_vm_barrier<(NSTAGE - 2) * G>();
+        else if (NSTAGE > 3 && ahead == 2) wait_vm_barrier<2 * G>();
+        else if (NSTAGE > 2 && ahead == 1) wait_vm_barrier<1 * G>();
+        else wait_vm_barrier<0>();
+        if (kt == 1) STAMP(2);
+        if (kt + NSTAGE - 1 < nkt) stage(kt + NSTAGE - 1, fill);
+        if (kt == 0) STAMP(1);
+        compute(smem + slot * STAGE);
+        slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        fill = fill + 1 == NSTAGE ? 0 : fill + 1;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done with the ring
 
-    // ---- epilogue: lane holds 4 consecutive n of row m per accumulator
+    STAMP(3);
+    // ---- epilogue through LDS (see header)
+    if (OUT_BF16) {
+        // whole 256 x 256 bf16 tile, rows padded to 528 B (16-byte aligned, 2-way write conflicts at most)
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int m = m0 + wm * 128 + mt * 16 + frow;
-        if (m >= a.M) continue;
-        const int64_t orow = (int64_t)(m / a.o_rpb) * a.o_bs + (int64_t)(m % a.o_rpb) * a.o_rs + a.o_off;
-        const float* rrow = a.res ? a.res + (int64_t)(m % a.res_rows) * a.ldr : nullptr;
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ml = wm * 128 + mt * 16 + frow;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-            if (n >= a.N) continue;
-            gemm_epilogue_store<GELU, OUT_BF16>(a, acc[nt][mt], m, n, orow, rrow);
+            for (int nt = 0; nt < 4; ++nt) {
+                const int nl = wn * 64 + nt * 16 + fq * 4;
+                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], m0 + ml, n0 + nl);
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x4*>(smem + ml * EP_ROW_BF16 + nl * 2) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int LPR = BN / 8, RPI = 64 / LPR, ROWS_W = 256 / NW;  // lanes per row, rows per instruction, rows per wave
+        const int rsub = lane / LPR, cch = lane % LPR;
+        if (n0 + cch * 8 < a.N) {
+            const int mfirst = m0 + wave * ROWS_W + rsub;
+            int oq = mfirst / a.o_rpb, orem = mfirst % a.o_rpb;  // row map, stepped incrementally
+#pragma unroll 4
+            for (int i = 0; i < ROWS_W / RPI; ++i) {
+                const int ml = wave * ROWS_W + i * RPI + rsub;
+                if (m0 + ml < a.M) {
+                    const int64_t orow = (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs + a.o_off;
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + ml * EP_ROW_BF16 + cch * 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + orow + n0 + cch * 8) = v;
+                }
+                orem += RPI;
+                while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
+            }
+        }
+    } else {
+        // fp32 output (+ fp32 residual): two passes of 128 rows, rows padded to 1040 B
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (wm == half) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int ml = mt * 16 + frow;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int nl = wn * 64 + nt * 16 + fq * 4;
+                        const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], m0 + half * 128 + ml, n0 + nl);
+                        *reinterpret_cast<f32x4*>(smem + ml * EP_ROW_F32 + nl * 4) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int LPR = BN / 4, RPI = 64 / LPR, ROWS_W = 128 / NW;
+            const int rsub = lane / LPR, cch = lane % LPR;
+            if (n0 + cch * 4 < a.N) {
+                const int mfirst = m0 + half * 128 + wave * ROWS_W + rsub;
+                int oq = mfirst / a.o_rpb, orem = mfirst % a.o_rpb;
+                int rrem = a.res ? mfirst % a.res_rows : 0;
+#pragma unroll 4
+                for (int i = 0; i < ROWS_W / RPI; ++i) {
+                    const int ml = wave * ROWS_W + i * RPI + rsub;
+                    if (mfirst + i * RPI < a.M) {
+                        const int64_t orow = (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs + a.o_off;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * EP_ROW_F32 + cch * 16);
+                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (int64_t)rrem * a.ldr + n0 + cch * 4);
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + n0 + cch * 4) = v;
+                    }
+                    orem += RPI;
+                    while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
+                    rrem += RPI;
+                    while (rrem >= a.res_rows) rrem -= a.res_rows;
+                }
+            }
         }
     }
+    STAMP(4);
+#ifdef ASRK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+#endif
 }
 
-template <bool GELU, bool OUT_BF16>
-int launch(const GemmArgs& a, hipStream_t st) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const size_t lds = 2 * STAGE_BYTES;
-    auto kern = gemm256_kernel<GELU, OUT_BF16>;
+template <int WN, int BK, int NSTAGE, bool GELU, bool OUT_BF16>
+int launch(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    constexpr int BN = 64 * WN;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    static const int forced = [] { const char* e = getenv("ASRK_GEMM_NSPLIT"); return e ? atoi(e) : 0; }();
+    int ns = 1;
+    if (forced > 0 && (forced == 1 || forced == 2 || forced == 4 || forced == 8) && tiles_n % forced == 0) ns = forced;
+    a.nsplit = ns;
+    const int tm_per = (tiles_m + 8 / ns - 1) / (8 / ns);
+    const int tiles = 8 * tm_per * (tiles_n / ns);
+    constexpr size_t ring = (size_t)NSTAGE * (256 + BN) * BK * 2;
+    constexpr size_t ep = (size_t)256 * (BN * 2 + 16) > (size_t)128 * (BN * 4 + 16) ? (size_t)256 * (BN * 2 + 16)
+                                                                                     : (size_t)128 * (BN * 4 + 16);
+    constexpr size_t lds = ring > ep ? ring : ep;
+    static_assert(lds <= (WN == 4 ? 163840 : 81920), "LDS budget");
+    auto kern = gemm256_kernel<WN, BK, NSTAGE, GELU, OUT_BF16>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ASRK_ERR_HIP;
     AsrkProfScope prof(ASRK_PROF_GEMM, 2.0 * a.M * a.N * a.K, st);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(128 * WN), lds, st, a);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+template <int WN, int BK, int NSTAGE>
+int dispatch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
+    if (gelu) return out_bf16 ? launch<WN, BK, NSTAGE, true, true>(a, st) : launch<WN, BK, NSTAGE, true, false>(a, st);
+    return out_bf16 ? launch<WN, BK, NSTAGE, false, true>(a, st) : launch<WN, BK, NSTAGE, false, false>(a, st);
 }
 
 }  // namespace
 
 // Arguments are validated by asrk_gemm_launch (asrk_gemm.hip), which dispatches here.
 int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
-    if (a.splits != 1) return ASRK_ERR_SHAPE;
-    if (gelu) return out_bf16 ? launch<true, true>(a, st) : launch<true, false>(a, st);
-    return out_bf16 ? launch<false, true>(a, st) : launch<false, false>(a, st);
+    if (a.splits != 1 || (a.N % 8) != 0) return ASRK_ERR_SHAPE;
+    // ASRK_GEMM_CFG (A/B measurements only): 0 = 256x256 BK 64 x 2 stages, 1 = 256x256 BK 32 x 4, 3 = 256x128 BK 32 x 3
+    static const int cfg = [] { const char* e = getenv("ASRK_GEMM_CFG"); return e ? atoi(e) : 0; }();
+    if (cfg == 1) return dispatch<4, 32, 4>(a, gelu, out_bf16, st);
+    if (cfg == 3) return dispatch<2, 32, 3>(a, gelu, out_bf16, st);
+    return dispatch<4, 64, 2>(a, gelu, out_bf16, st);
 }

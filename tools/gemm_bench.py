@@ -1,0 +1,66 @@
+"""Micro-benchmark of asrk_gemm_bf16 at the encoder's shapes (B = 64 clips -> M = 96000).
+
+    python tools/gemm_bench.py [--iters 20] [--shapes qkv,out,fc1,fc2] [--M 96000]
+Set ASRK_GEMM_TILE=128|256 to force a tile size.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from asr_amd import _lib  # noqa: E402
+
+SHAPES = {
+    # name: (N, K, gelu, out_bf16, bias, res)
+    "qkv": (2304, 768, 0, 1, 1, 0),
+    "out": (768, 768, 0, 0, 1, 1),
+    "fc1": (3072, 768, 1, 1, 1, 0),
+    "fc1_nogelu": (3072, 768, 0, 1, 1, 0),
+    "fc2": (768, 3072, 0, 0, 1, 1),
+    "sq4k": (4096, 4096, 0, 1, 0, 0),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--M", type=int, default=96000)
+    ap.add_argument("--shapes", default="qkv,out,fc1,fc1_nogelu,fc2")
+    args = ap.parse_args()
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name in args.shapes.split(","):
+        N, K, gelu, obf, ub, ur = SHAPES[name]
+        M = 4096 if name == "sq4k" else args.M
+        x = (torch.randn((M, K), device="cuda") * 0.5).to(torch.bfloat16)
+        w = (torch.randn((N, K), device="cuda") * K ** -0.5).to(torch.bfloat16)
+        bias = torch.randn((N,), device="cuda") if ub else None
+        res = torch.randn((M, N), device="cuda") if ur else None
+        out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16 if obf else torch.float32)
+        target = res if ur else out  # residual epilogues run in place, like the encoder
+
+        def run():
+            rc = lib.asrk_gemm_bf16(p(x), K, p(w), p(bias), p(res), N, M, p(target), N, obf, M, N, K, gelu, 1.0, st)
+            assert rc == 0, rc
+
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        tf = 2.0 * M * N * K / us / 1e6
+        print(f"{name:11s} M={M} N={N} K={K}: {us:8.1f} us  {tf:7.1f} TFLOP/s  (tile={os.environ.get('ASRK_GEMM_TILE', 'auto')})",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
