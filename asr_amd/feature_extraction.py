@@ -179,6 +179,22 @@ class LogMelFeatureExtractor:
         if isinstance(raw_speech, torch.Tensor):
             raw_speech = raw_speech.numpy()
 
+        host, lengths, target = self.prepare_host(raw_speech, truncation=truncation, pad_to_multiple_of=pad_to_multiple_of,
+                                                   padding=padding, max_length=max_length)
+        dev = self._device(device)
+        with torch.cuda.device(dev):
+            wave = host.to(dev, non_blocking=True)
+            feats = self.extract_from_device(wave)
+        res = BatchFeature(input_features=feats)
+        if return_attention_mask:
+            res["attention_mask"] = torch.from_numpy(self.frame_mask(lengths, target)).to(dev, non_blocking=True)
+        return self._convert(res, return_tensors)
+
+    # ------------------------------------------------------------------ host-side steps (no GPU needed)
+    def prepare_host(self, raw_speech, truncation: bool = True, pad_to_multiple_of: Optional[int] = None,
+                     padding: Optional[str] = "max_length", max_length: Optional[int] = None):
+        """Batching, truncation and right-padding of HF __call__ (:278-307; sequence_utils.py:187-220,
+        296-337).  Returns (float32 tensor [B, target], pinned when a GPU is present; lengths; target)."""
         is_batched_numpy = isinstance(raw_speech, np.ndarray) and raw_speech.ndim > 1
         if is_batched_numpy and raw_speech.ndim > 2:
             raise ValueError(f"Only mono-channel audio is supported for input to {self}")
@@ -188,8 +204,6 @@ class LogMelFeatureExtractor:
         )
         clips: Sequence = raw_speech if is_batched else [raw_speech]
         clips = [np.asarray(c.cpu() if isinstance(c, torch.Tensor) else c, dtype=np.float32).reshape(-1) for c in clips]
-
-        # ---- truncate / pad (sequence_utils.py:187-220, 296-337)
         max_length = max_length if max_length else self.n_samples
         if pad_to_multiple_of is not None and max_length % pad_to_multiple_of != 0:
             max_length = (max_length // pad_to_multiple_of + 1) * pad_to_multiple_of
@@ -204,8 +218,7 @@ class LogMelFeatureExtractor:
         else:
             raise ValueError("padding must be 'max_length' or 'longest': the device kernel works on one dense batch")
         B = len(clips)
-        dev = self._device(device)
-        host = torch.empty((B, target), dtype=torch.float32, pin_memory=True)
+        host = torch.empty((B, target), dtype=torch.float32, pin_memory=torch.cuda.is_available())
         host_np = host.numpy()
         lengths = np.empty((B,), dtype=np.int64)
         for i, c in enumerate(clips):
@@ -213,19 +226,14 @@ class LogMelFeatureExtractor:
             host_np[i, :n] = c[:n]
             host_np[i, n:] = self.padding_value
             lengths[i] = n
-        with torch.cuda.device(dev):
-            wave = host.to(dev, non_blocking=True)
-            feats = self.extract_from_device(wave)
-        res = BatchFeature(input_features=feats)
-        if return_attention_mask:
-            # sample mask [:, ::hop], trimmed when the length is not a multiple of hop (HF :332-341)
-            n_mask = (target + self.hop_length - 1) // self.hop_length
-            if target % self.hop_length != 0:
-                n_mask -= 1
-            frame_idx = np.arange(n_mask, dtype=np.int64)[None, :] * self.hop_length
-            mask = (frame_idx < lengths[:, None]).astype(np.int32)
-            res["attention_mask"] = torch.from_numpy(mask).to(dev, non_blocking=True)
-        return self._convert(res, return_tensors)
+        return host, lengths, target
+
+    def frame_mask(self, lengths: np.ndarray, target: int) -> np.ndarray:
+        """int32 [B, target // 160]: the sample mask taken every hop, trimmed when `target` is not a
+        multiple of the hop (HF :332-341)."""
+        n_mask = target // self.hop_length
+        frame_idx = np.arange(n_mask, dtype=np.int64)[None, :] * self.hop_length
+        return (frame_idx < np.asarray(lengths)[:, None]).astype(np.int32)
 
     @staticmethod
     def _convert(res: BatchFeature, return_tensors) -> BatchFeature:

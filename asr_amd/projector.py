@@ -44,14 +44,14 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
 
 class _ProjectorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, w1, b1, w2, b2, out_dtype):
+    def forward(ctx, x, gamma, w1, b1, w2, b2, out_dtype, grad_enabled):
         lib = _lib.load()
         A, T = w1.shape[1], w1.shape[0]
         x2 = x.detach().reshape(-1, A).to(torch.float32).contiguous()
         M = x2.shape[0]
         dims = _lib.ProjectorDims(A, T)
         ps = [t.detach().to(torch.float32).contiguous() for t in (gamma, w1, b1, w2, b2)]
-        need_grad = any(ctx.needs_input_grad[:6])
+        need_grad = grad_enabled and any(ctx.needs_input_grad[:6])  # no saved activations under no_grad
         out = torch.empty((M, T), dtype=out_dtype, device=x2.device)
         with torch.cuda.device(x2.device):
             ws = _workspace(x2.device, lib.asrk_projector_workspace_bytes(ctypes.byref(dims), M))
@@ -90,7 +90,7 @@ class _ProjectorFn(torch.autograd.Function):
                                                    M, _lib.ptr(saved), ctypes.byref(gstruct), _lib.ptr(gx), _lib.ptr(x2),
                                                    _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                        "asrk_projector_backward")
-        return (gx.reshape(ctx.x_shape) if gx is not None else None, g[0], g[1], g[2], g[3], g[4], None)
+        return (gx.reshape(ctx.x_shape) if gx is not None else None, g[0], g[1], g[2], g[3], g[4], None, None)
 
 
 class AudioProjector(nn.Module):
@@ -115,4 +115,4 @@ class AudioProjector(nn.Module):
             out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and
                                            torch.get_autocast_gpu_dtype() == torch.bfloat16) else torch.float32
         return _ProjectorFn.apply(audio_features, self.norm.weight, self.linear_1.weight, self.linear_1.bias,
-                                  self.linear_2.weight, self.linear_2.bias, out_dtype)
+                                  self.linear_2.weight, self.linear_2.bias, out_dtype, torch.is_grad_enabled())
