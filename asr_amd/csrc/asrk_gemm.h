@@ -24,6 +24,7 @@ struct GemmArgs {
     int splits;
     int64_t o_split;
     int nsplit;  // set by the 256-tile launcher: n-groups of the XCD grid (1, 2, 4, 8)
+    int skew;    // set by the 256-tile launcher: start-up phase skew, in units of s_sleep(127) per phase step
 };
 
 // out = (((acc + bias) -> gelu?) * alpha [* gelu'(pre)]) + res
@@ -31,12 +32,11 @@ int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st
 int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);  // 256x256 tiles, splits == 1
 
 // Element part of the epilogue (everything except residual and store) for 4 consecutive n of row m.
+// `bv` is the bias of those 4 columns, loaded once by the caller (it does not depend on the row: a load
+// per accumulator made the epilogue a chain of 32 dependent L2 round trips, 9.8 k cycles per tile).
 template <bool GELU>
-__device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v, int m, int n) {
-    if (a.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
+__device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v, f32x4 bv, int m, int n) {
+    v += bv;
     if (GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
@@ -53,12 +53,9 @@ __device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v,
 // Shared epilogue: v = 4 consecutive n (n .. n+3) of output row m.  `orow` is the element offset
 // of the output row, `rrow` the residual row (or null).
 template <bool GELU, bool OUT_BF16>
-__device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& a, f32x4 v, int m, int n, int64_t orow,
+__device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& a, f32x4 v, f32x4 bv, int m, int n, int64_t orow,
                                                     const float* rrow) {
-    if (a.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
+    v += bv;
     if (GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);

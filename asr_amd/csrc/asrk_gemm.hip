@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
     }
 
     // ---- epilogue: lane holds n = nb + 0..3 (4 consecutive) for row m
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+        bv[nt] = (a.bias && n < a.N) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wm * 64 + mt * 16 + frow;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn * 64 + nt * 16 + fq * 4;
             if (n >= a.N) continue;
-            gemm_epilogue_store<GELU, OUT_BF16>(a, acc[nt][mt], m, n, orow, rrow);
+            gemm_epilogue_store<GELU, OUT_BF16>(a, acc[nt][mt], bv[nt], m, n, orow, rrow);
         }
     }
 }

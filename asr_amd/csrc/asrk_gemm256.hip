@@ -140,6 +140,13 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) 
         }
     };
 
+    // ---- start-up skew (first round of workgroups only): all tiles of a GEMM take the same time, so
+    //      without it every CU reaches its epilogue at the same moment and the output stores arrive as
+    //      one HBM write burst per round; spreading the phases keeps the stores under the other CUs' K loops.
+    if (a.skew > 0 && blockIdx.x < 256) {
+        const int n = ((blockIdx.x >> 3) & 7) * a.skew;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int nkt = a.K / BK;
     STAMP(0);
 #pragma unroll
@@ -163,6 +170,12 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) 
 
     STAMP(3);
     // ---- epilogue through LDS (see header)
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+        bv[nt] = (a.bias && n < a.N) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (OUT_BF16) {
         // whole 256 x 256 bf16 tile, rows padded to 528 B (16-byte aligned, 2-way write conflicts at most)
 #pragma unroll
@@ -171,14 +184,16 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) 
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int nl = wn * 64 + nt * 16 + fq * 4;
-                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], m0 + ml, n0 + nl);
+                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + ml, n0 + nl);
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
                 *reinterpret_cast<bf16x4*>(smem + ml * EP_ROW_BF16 + nl * 2) = o;
             }
         }
+        STAMP(6);
         __syncthreads();
+        STAMP(7);
         constexpr int LPR = BN / 8, RPI = 64 / LPR, ROWS_W = 256 / NW;  // lanes per row, rows per instruction, rows per wave
         const int rsub = lane / LPR, cch = lane % LPR;
         if (n0 + cch * 8 < a.N) {
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) 
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const int nl = wn * 64 + nt * 16 + fq * 4;
-                        const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], m0 + half * 128 + ml, n0 + nl);
+                        const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + half * 128 + ml, n0 + nl);
                         *reinterpret_cast<f32x4*>(smem + ml * EP_ROW_F32 + nl * 4) = v;
                     }
                 }
@@ -253,6 +268,8 @@ int launch(const GemmArgs& a_in, hipStream_t st) {
     int ns = 1;
     if (forced > 0 && (forced == 1 || forced == 2 || forced == 4 || forced == 8) && tiles_n % forced == 0) ns = forced;
     a.nsplit = ns;
+    static const int skew = [] { const char* e = getenv("ASRK_GEMM_SKEW"); return e ? atoi(e) : 0; }();
+    a.skew = skew;
     const int tm_per = (tiles_m + 8 / ns - 1) / (8 / ns);
     const int tiles = 8 * tm_per * (tiles_n / ns);
     constexpr size_t ring = (size_t)NSTAGE * (256 + BN) * BK * 2;

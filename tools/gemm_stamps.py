@@ -39,11 +39,10 @@ d = np.diff(t, axis=1)
 print(f"M={M} N={N} K={K} blocks={nb}; s_memtime ticks (100 MHz => 1 tick = 10 ns)")
 for i, nme in enumerate(names):
     print(f"  {nme:22s} median {np.median(d[:, i]):8.0f}  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+ep = buf[:, [3, 6, 7, 4]].astype(np.int64)
+if ep[:, 1].max() > 0:
+    de = np.diff(ep, axis=1)
+    for i, nme in enumerate(["  epi: value+LDS write", "  epi: barrier", "  epi: LDS read+store"]):
+        print(f"  {nme:22s} median {np.median(de[:, i]):8.0f}")
 tot = t[:, 5] - t[:, 0]
 print(f"  total per block        median {np.median(tot):8.0f}; kernel span {t[:, 5].max() - t0} ticks")
-xcc = buf[:, 6].astype(np.int64)
-print("  xcc of blocks 0..15:", xcc[:16].tolist(), " blockIdx%8 == xcc-pattern consistent:",
-      bool(np.all(xcc[np.arange(nb) % 8 == 0] == xcc[0])))
-start = t[:, 0] - t0
-order = np.argsort(start)
-print("  start times of first 10 / last 5 blocks:", start[order[:10]].tolist(), start[order[-5:]].tolist())
