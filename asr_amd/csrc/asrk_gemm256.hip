@@ -26,10 +26,15 @@
 #ifdef ASRK_STAMPS
 // Diagnostic build only (tools/build_diag.sh): per-workgroup s_memtime stamps, never in the product.
 __device__ unsigned long long g_stamps[16384 * 8];
+__device__ unsigned long long g_wall[16384 * 2];  // s_memrealtime (100 MHz) at stamps 0 and 4
 extern "C" int asrk_debug_read_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
 }
-#define STAMP(i) do { if (tid == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (tid == 0 && blockIdx.x < 16384) { g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0 || (i) == 4) g_wall[blockIdx.x * 2 + ((i) >> 2)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int asrk_debug_read_wall(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wall), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -41,6 +46,129 @@ constexpr int BM = 256;
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// Epilogue through LDS (see header): acc[nt][mt] of wave (wm, wn) -> out.  Every wave of the workgroup
+// must have finished reading the K ring before it enters.
+template <int WN, bool GELU, bool OUT_BF16>
+__device__ __forceinline__ void epilogue256(const GemmArgs& a, f32x4 (&acc)[4][8], char* smem, int m0, int n0) {
+    constexpr int NW = 2 * WN, BN = 64 * WN;
+    constexpr int EP_ROW_BF16 = BN * 2 + 16;  // epilogue staging row strides (bytes)
+    constexpr int EP_ROW_F32 = BN * 4 + 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15;
+    const int fq = lane >> 4;
+    STAMP(3);
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+        bv[nt] = (a.bias && n < a.N) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (OUT_BF16) {
+        // whole 256 x 256 bf16 tile, rows padded to 528 B (16-byte aligned, 2-way write conflicts at most)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ml = wm * 128 + mt * 16 + frow;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int nl = wn * 64 + nt * 16 + fq * 4;
+                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + ml, n0 + nl);
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x4*>(smem + ml * EP_ROW_BF16 + nl * 2) = o;
+            }
+        }
+        STAMP(6);
+        __syncthreads();
+        STAMP(7);
+        constexpr int LPR = BN / 8, RPI = 64 / LPR, ROWS_W = 256 / NW;  // lanes per row, rows per instruction, rows per wave
+        const int rsub = lane / LPR, cch = lane % LPR;
+        if (n0 + cch * 8 < a.N) {
+            const int mfirst = m0 + wave * ROWS_W + rsub;
+            int oq = mfirst / a.o_rpb, orem = mfirst % a.o_rpb;  // row map, stepped incrementally
+#pragma unroll 4
+            for (int i = 0; i < ROWS_W / RPI; ++i) {
+                const int ml = wave * ROWS_W + i * RPI + rsub;
+                if (m0 + ml < a.M) {
+                    const int64_t orow = (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs + a.o_off;
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + ml * EP_ROW_BF16 + cch * 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + orow + n0 + cch * 8) = v;
+                }
+                orem += RPI;
+                while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
+            }
+        }
+    } else {
+        // fp32 output (+ fp32 residual): two passes of 128 rows, rows padded to 1040 B.  The residual rows a
+        // lane will add are fetched into registers ahead of time (pass 0: before the accumulators are
+        // staged; pass 1: row by row as pass 0 consumes its copies), so their HBM latency runs under the
+        // LDS staging and the barriers instead of in front of every store.
+        constexpr int LPR = BN / 4, RPI = 64 / LPR, ROWS_W = 128 / NW, NIT = ROWS_W / RPI;
+        const int rsub = lane / LPR, cch = lane % LPR;
+        const bool col_ok = n0 + cch * 4 < a.N;
+        f32x4 rv[NIT];
+        int rrem_next = 0;  // residual row of (pass, i) being prefetched, stepped incrementally
+        auto res_row = [&](int half, int i) -> f32x4 {
+            // rows are visited in order (half 0: i = 0..NIT-1, then half 1); rrem_next is set at i == 0
+            const int m = m0 + half * 128 + wave * ROWS_W + rsub + i * RPI;
+            if (i == 0) rrem_next = m % a.res_rows;
+            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col_ok && m < a.M) r = *reinterpret_cast<const f32x4*>(a.res + (int64_t)rrem_next * a.ldr + n0 + cch * 4);
+            rrem_next += RPI;
+            while (rrem_next >= a.res_rows) rrem_next -= a.res_rows;
+            return r;
+        };
+        if (a.res) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) rv[i] = res_row(0, i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (wm == half) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int ml = mt * 16 + frow;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int nl = wn * 64 + nt * 16 + fq * 4;
+                        const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + half * 128 + ml, n0 + nl);
+                        *reinterpret_cast<f32x4*>(smem + ml * EP_ROW_F32 + nl * 4) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (half == 0) STAMP(6);
+            const int mfirst = m0 + half * 128 + wave * ROWS_W + rsub;
+            int oq = mfirst / a.o_rpb, orem = mfirst % a.o_rpb;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int ml = wave * ROWS_W + i * RPI + rsub;
+                if (col_ok && mfirst + i * RPI < a.M) {
+                    const int64_t orow = (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs + a.o_off;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * EP_ROW_F32 + cch * 16) + rv[i];
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + n0 + cch * 4) = v;
+                }
+                if (half == 0 && a.res) rv[i] = res_row(1, i);
+                orem += RPI;
+                while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
+            }
+            if (half == 0) STAMP(7);
+        }
+    }
+    STAMP(4);
+#ifdef ASRK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+#endif
 }
 
 // WN = waves along n (4: 256 x 256 tile, 512 threads, 1 workgroup / CU;  2: 256 x 128 tile, 256 threads,
@@ -56,8 +184,6 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) 
     constexpr int G = GX + GW;
     constexpr int RPR = NTHR / CPR;         // rows staged per round of NTHR lanes
     constexpr int KS = BK / 32;             // MFMA k-steps per stage
-    constexpr int EP_ROW_BF16 = BN * 2 + 16;  // epilogue staging row strides (bytes)
-    constexpr int EP_ROW_F32 = BN * 4 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSTAGE][X slice | W slice]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -168,95 +294,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) 
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everyone is done with the ring
 
-    STAMP(3);
-    // ---- epilogue through LDS (see header)
-    f32x4 bv[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-        bv[nt] = (a.bias && n < a.N) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (OUT_BF16) {
-        // whole 256 x 256 bf16 tile, rows padded to 528 B (16-byte aligned, 2-way write conflicts at most)
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int ml = wm * 128 + mt * 16 + frow;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int nl = wn * 64 + nt * 16 + fq * 4;
-                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + ml, n0 + nl);
-                bf16x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-                *reinterpret_cast<bf16x4*>(smem + ml * EP_ROW_BF16 + nl * 2) = o;
-            }
-        }
-        STAMP(6);
-        __syncthreads();
-        STAMP(7);
-        constexpr int LPR = BN / 8, RPI = 64 / LPR, ROWS_W = 256 / NW;  // lanes per row, rows per instruction, rows per wave
-        const int rsub = lane / LPR, cch = lane % LPR;
-        if (n0 + cch * 8 < a.N) {
-            const int mfirst = m0 + wave * ROWS_W + rsub;
-            int oq = mfirst / a.o_rpb, orem = mfirst % a.o_rpb;  // row map, stepped incrementally
-#pragma unroll 4
-            for (int i = 0; i < ROWS_W / RPI; ++i) {
-                const int ml = wave * ROWS_W + i * RPI + rsub;
-                if (m0 + ml < a.M) {
-                    const int64_t orow = (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs + a.o_off;
-                    const uint4 v = *reinterpret_cast<const uint4*>(smem + ml * EP_ROW_BF16 + cch * 16);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + orow + n0 + cch * 8) = v;
-                }
-                orem += RPI;
-                while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
-            }
-        }
-    } else {
-        // fp32 output (+ fp32 residual): two passes of 128 rows, rows padded to 1040 B
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half) __syncthreads();
-            if (wm == half) {
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    const int ml = mt * 16 + frow;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const int nl = wn * 64 + nt * 16 + fq * 4;
-                        const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + half * 128 + ml, n0 + nl);
-                        *reinterpret_cast<f32x4*>(smem + ml * EP_ROW_F32 + nl * 4) = v;
-                    }
-                }
-            }
-            __syncthreads();
-            constexpr int LPR = BN / 4, RPI = 64 / LPR, ROWS_W = 128 / NW;
-            const int rsub = lane / LPR, cch = lane % LPR;
-            if (n0 + cch * 4 < a.N) {
-                const int mfirst = m0 + half * 128 + wave * ROWS_W + rsub;
-                int oq = mfirst / a.o_rpb, orem = mfirst % a.o_rpb;
-                int rrem = a.res ? mfirst % a.res_rows : 0;
-#pragma unroll 4
-                for (int i = 0; i < ROWS_W / RPI; ++i) {
-                    const int ml = wave * ROWS_W + i * RPI + rsub;
-                    if (mfirst + i * RPI < a.M) {
-                        const int64_t orow = (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs + a.o_off;
-                        f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * EP_ROW_F32 + cch * 16);
-                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (int64_t)rrem * a.ldr + n0 + cch * 4);
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + n0 + cch * 4) = v;
-                    }
-                    orem += RPI;
-                    while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
-                    rrem += RPI;
-                    while (rrem >= a.res_rows) rrem -= a.res_rows;
-                }
-            }
-        }
-    }
-    STAMP(4);
-#ifdef ASRK_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(5);
-#endif
+    epilogue256<WN, GELU, OUT_BF16>(a, acc, smem, m0, n0);
 }
 
 template <int WN, int BK, int NSTAGE, bool GELU, bool OUT_BF16>
