@@ -30,6 +30,7 @@ struct GemmArgs {
 // out = (((acc + bias) -> gelu?) * alpha [* gelu'(pre)]) + res
 int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);
 int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);  // 256x256 tiles, splits == 1
+int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);  // same, persistent workgroups
 
 // Element part of the epilogue (everything except residual and store) for 4 consecutive n of row m.
 // `bv` is the bias of those 4 columns, loaded once by the caller (it does not depend on the row: a load
@@ -42,7 +43,7 @@ __device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v,
         for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
     }
     v *= a.alpha;
-    if (a.dg_pre) {
+    if (a.dg_pre && m < a.M && n < a.N) {
         const bf16x4 pz = *reinterpret_cast<const bf16x4*>(a.dg_pre + (int64_t)m * a.ld_dg + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad((float)pz[j]);
@@ -61,7 +62,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& a, f32x4 v, 
         for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
     }
     v *= a.alpha;
-    if (a.dg_pre) {
+    if (a.dg_pre && m < a.M && n < a.N) {
         const bf16x4 pz = *reinterpret_cast<const bf16x4*>(a.dg_pre + (int64_t)m * a.ld_dg + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad((float)pz[j]);

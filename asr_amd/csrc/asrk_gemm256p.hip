@@ -1,0 +1,297 @@
+// Persistent form of the 256 x 256-tile bf16 MFMA GEMM (contract of asrk_gemm.hip, tile and K loop of
+// asrk_gemm256.hip): one 512-thread workgroup per CU walks a list of tiles, and the K stream never stops
+// at a tile boundary.
+//
+//   * The LDS ring (2 stages x 64 K-columns x (256 + 256) rows = 128 KiB) is treated as one long stream of
+//     K slices: while the last slice of tile i is multiplied, slice 0 of tile i+1 is already being written
+//     into the other slot by global_load_lds, so a tile does not start with an exposed HBM/L2 round trip
+//     (5-8 k cycles of ~56 k per tile in the one-tile-per-workgroup kernel).
+//   * The epilogue therefore cannot borrow the ring.  Each wave transposes its own 128 x 64 block through a
+//     private 4 KiB LDS patch (8 waves x 4 KiB = the 32 KiB the ring leaves free), 16 rows at a time:
+//     accumulator layout in, whole 128-byte (bf16) / 256-byte (fp32) row segments out, 16 B per lane.  A wave's
+//     LDS operations execute in order, so this needs no workgroup barrier at all: the waves drift apart in
+//     the epilogue and meet again at the first barrier of the next tile.
+//   * fp32 residual rows are fetched one 16-row group ahead of the group being stored.
+//
+// Tile order: workgroup b runs on XCD b & 7 (verified with HW_REG_XCC_ID); XCD x owns a contiguous run of
+// m panels and walks its tiles n-fastest, 32 tiles (one per CU of the XCD) at a time, so the 32 concurrent
+// tiles of an XCD share a few X panels and the whole weight matrix in that XCD's L2.
+#include "asrk_common.h"
+#include "asrk_gemm.h"
+#include "asrk_prof.h"
+
+#ifdef ASRK_STAMPS
+__device__ unsigned long long g_pstamps[1024 * 8];
+extern "C" int asrk_debug_read_pstamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pstamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define PSTAMP(i) do { if (tid == 0 && blockIdx.x < 1024) g_pstamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64, NTHR = 512;
+constexpr int RB = BK * 2;           // bytes per LDS row
+constexpr int CPR = RB / 16;         // 16-byte chunks per row
+constexpr int XOPER = BM * RB;       // bytes of the X slice
+constexpr int STAGE = XOPER + BN * RB;
+constexpr int GX = BM * CPR / NTHR, GW = BN * CPR / NTHR;
+constexpr int RPR = NTHR / CPR;      // rows staged per round of NTHR lanes
+constexpr int RING = 2 * STAGE;
+constexpr int PATCH = 4096;          // private epilogue patch per wave
+constexpr int LDS_BYTES = RING + 8 * PATCH;
+static_assert(LDS_BYTES == 163840, "uses all of the CU's LDS");
+
+__device__ __forceinline__ void wait_all_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Orders this wave's LDS stores before its following LDS loads of other lanes' data (the hardware runs a
+// wave's LDS operations in order; this only stops the compiler from moving them).
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One wave's 128 x 64 block (rows mw.., columns nw..) from accumulators to memory.
+template <bool GELU, bool OUT_BF16>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4][8], char* patch, int mw, int nw, int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = nw + nt * 16 + fq * 4;
+        bv[nt] = (a.bias && n < a.N) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (OUT_BF16) {
+        constexpr int ROWB = 144;  // 128 B of data + 16 B pad
+        const int r8 = lane >> 3, c8 = lane & 7;
+        const bool col_ok = nw + c8 * 8 < a.N;
+        int oq = (mw + r8) / a.o_rpb, orem = (mw + r8) % a.o_rpb;  // row map of the rows this lane stores, stepped by 8
+        bf16_t* const out = reinterpret_cast<bf16_t*>(a.out) + a.o_off + nw + c8 * 8;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], mw + mt * 16 + frow, nw + nt * 16 + fq * 4);
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x4*>(patch + frow * ROWB + (nt * 16 + fq * 4) * 2) = o;
+            }
+            wave_lds_order();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = h * 8 + r8;
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + row * ROWB + c8 * 16);
+                if (col_ok && mw + mt * 16 + row < a.M)
+                    *reinterpret_cast<uint4*>(out + (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs) = v;
+                orem += 8;
+                while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
+            }
+            wave_lds_order();
+        }
+    } else {
+        // [16][64] fp32 patch, exactly 4 KiB: 16-byte chunk c of row r lives at chunk c ^ r (conflict-free for
+        // the accumulator-layout ds_write_b128 and for the row-layout ds_read_b128)
+        const int r4 = lane >> 4, c16 = lane & 15;
+        const bool col_ok = nw + c16 * 4 < a.N;
+        int oq = (mw + r4) / a.o_rpb, orem = (mw + r4) % a.o_rpb;  // rows this lane stores, stepped by 4
+        float* const out = reinterpret_cast<float*>(a.out) + a.o_off + nw + c16 * 4;
+        // residual rows, fetched one 16-row group ahead
+        int rrem = a.res ? (mw + r4) % a.res_rows : 0;
+        const float* const res = a.res ? a.res + nw + c16 * 4 : nullptr;
+        f32x4 rv[2][4];
+        auto fetch = [&](int mt, f32x4 (&dst)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (res && col_ok && mw + mt * 16 + i * 4 + r4 < a.M)
+                    dst[i] = *reinterpret_cast<const f32x4*>(res + (int64_t)rrem * a.ldr);
+                rrem += 4;
+                while (rrem >= a.res_rows) rrem -= a.res_rows;
+            }
+        };
+        fetch(0, rv[0]);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            if (mt + 1 < 8) fetch(mt + 1, rv[(mt + 1) & 1]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], mw + mt * 16 + frow, nw + nt * 16 + fq * 4);
+                *reinterpret_cast<f32x4*>(patch + frow * 256 + (((nt * 4 + fq) ^ frow) << 4)) = v;
+            }
+            wave_lds_order();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 4 + r4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c16 ^ row) << 4)) + rv[mt & 1][i];
+                if (col_ok && mw + mt * 16 + row < a.M)
+                    *reinterpret_cast<f32x4*>(out + (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs) = v;
+                orem += 4;
+                while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
+            }
+            wave_lds_order();
+        }
+    }
+}
+
+template <bool GELU, bool OUT_BF16>
+__global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][X slice | W slice] | 8 epilogue patches
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- this workgroup's tile list
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    const int tm_per = (tiles_m + 7) / 8;
+    const int tm_lo = xcd * tm_per;
+    const int tm_cnt = tiles_m - tm_lo < tm_per ? tiles_m - tm_lo : tm_per;
+    const int count = tm_cnt > 0 ? tm_cnt * tiles_n : 0;
+    if (lidx >= count) return;
+
+    // ---- per-thread staging sources of the current tile (GX rows of X and GW rows of W per slice)
+    const int srow = tid / CPR;
+    const int chunk = (tid % CPR) ^ (srow & 7);
+    const bf16_t* xp[GX];
+    const bf16_t* wp[GW];
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < GX; ++i) {
+            int m = m0 + srow + RPR * i;
+            m = m < a.M ? m : a.M - 1;
+            xp[i] = a.X + (int64_t)(m / a.x_rpb) * a.x_bs + (int64_t)(m % a.x_rpb) * a.x_rs + chunk * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            int n = n0 + srow + RPR * i;
+            n = n < a.N ? n : a.N - 1;
+            wp[i] = a.W + (int64_t)n * a.K + chunk * 8;
+        }
+    };
+    const int wave_lds = wave * 1024;
+    auto stage = [&](int kt, int slot) {
+        char* sb = smem + slot * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < GX; ++i) glds16(xp[i] + k0, sb + i * (NTHR * 16) + wave_lds);
+#pragma unroll
+        for (int i = 0; i < GW; ++i) glds16(wp[i] + k0, sb + XOPER + i * (NTHR * 16) + wave_lds);
+    };
+
+    f32x4 acc[4][8];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int x_off = (wm * 128 + frow) * RB;
+    const int w_off = XOPER + (wn * 64 + frow) * RB;
+    auto compute = [&](const char* sb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ (frow & 7)) << 4;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(sb + w_off + t * 16 * RB + coff);
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                bf16x8 xf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    xf[t] = *reinterpret_cast<const bf16x8*>(sb + x_off + (mh * 4 + t) * 16 * RB + coff);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[nt][mh * 4 + t] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[t], acc[nt][mh * 4 + t], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nkt = a.K / BK;
+    int t = lidx;
+    int m0 = (tm_lo + t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    set_sources(m0, n0);
+    PSTAMP(0);
+    stage(0, 0);
+    int slot = 0;
+#ifdef ASRK_STAMPS
+    int tile_no = 0;
+#endif
+    while (true) {
+        const int tnext = t + wgs_per_xcd;
+        const bool has_next = tnext < count;
+        int m0n = 0, n0n = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            // my loads of this slice have landed (and my stores of the previous tile have drained); after the
+            // barrier everyone's have, and everyone has finished reading the other slot
+            wait_all_barrier();
+#ifdef ASRK_STAMPS
+            if (kt == 0) { if (tile_no == 0) PSTAMP(1); else if (tile_no == 1) PSTAMP(5); }
+#endif
+            if (kt + 1 < nkt) {
+                stage(kt + 1, slot ^ 1);
+            } else if (has_next) {  // the K stream runs on into the next tile
+                m0n = (tm_lo + tnext / tiles_n) * BM;
+                n0n = (tnext % tiles_n) * BN;
+                set_sources(m0n, n0n);
+                stage(0, slot ^ 1);
+            }
+            compute(smem + slot * STAGE);
+            slot ^= 1;
+        }
+#ifdef ASRK_STAMPS
+        if (tile_no == 0) PSTAMP(2);
+#endif
+        epilogue_wave<GELU, OUT_BF16>(a, acc, smem + RING + wave * PATCH, m0 + wm * 128, n0 + wn * 64, lane);
+#ifdef ASRK_STAMPS
+        if (tile_no == 0) PSTAMP(3); else if (tile_no == 1) PSTAMP(6);
+        ++tile_no;
+#endif
+        if (!has_next) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        t = tnext;
+        m0 = m0n;
+        n0 = n0n;
+    }
+    PSTAMP(7);
+}
+
+template <bool GELU, bool OUT_BF16>
+int launch(const GemmArgs& a, hipStream_t st) {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 256;
+        return n;
+    }();
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const int per_xcd = ((tiles_m + 7) / 8) * tiles_n;  // tiles of the fullest XCD
+    int wgs_per_xcd = cus / 8;
+    if (per_xcd < wgs_per_xcd) wgs_per_xcd = per_xcd;
+    auto kern = gemm256p_kernel<GELU, OUT_BF16>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        return ASRK_ERR_HIP;
+    AsrkProfScope prof(ASRK_PROF_GEMM, 2.0 * a.M * a.N * a.K, st);
+    hipLaunchKernelGGL(kern, dim3(8 * wgs_per_xcd), dim3(NTHR), LDS_BYTES, st, a);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+}  // namespace
+
+// Arguments are validated by asrk_gemm_launch (asrk_gemm.hip); needs splits == 1, N % 8 == 0, K % 64 == 0.
+int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
+    if (a.splits != 1 || (a.N % 8) != 0 || (a.K % BK) != 0) return ASRK_ERR_SHAPE;
+    if (gelu) return out_bf16 ? launch<true, true>(a, st) : launch<true, false>(a, st);
+    return out_bf16 ? launch<false, true>(a, st) : launch<false, false>(a, st);
+}
