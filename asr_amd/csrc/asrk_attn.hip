@@ -16,6 +16,8 @@
 #include "asrk_gemm.h"
 #include "asrk_prof.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int HD = 64;       // head_dim (Whisper: always 64)
@@ -89,7 +91,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 
     const int nkt = (T + KT - 1) / KT;
     stage(0, 0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // MASKED (compile time) marks the ragged last tile: a run-time test inside one loop body is turned
+    // into 31 v_cndmask per tile by if-conversion
+    auto tile = [&](int kt, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
                 sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[mt], 0, 0, 0);
             }
         }
-        if (kt == nkt - 1 && (T % KT) != 0) {  // mask keys past the end of the clip
+        if (MASKED) {  // mask keys past the end of the clip
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * LOG2E);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
         const float mb = m_new * LOG2E;
         float psum = 0.f;
         bf16x8 pf[2][2];  // [mt][k-step s]: registers 8 s .. 8 s + 7
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(fmaf(sacc[mt][r], LOG2E, -mb));
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[mt][r], LOG2E, -mb));  // bare v_exp_f32: exp2f() adds a denormal-range rescale (5 VALU) per call
                 psum += p;
                 pf[mt][r >> 3][r & 7] = (bf16_t)p;
             }
@@ -160,7 +165,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
                     }
                     o[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[mt][s], o[ht], 0, 0, 0);
                 }
-    }
+    };
+    const int nfull = (T % KT) != 0 ? nkt - 1 : nkt;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nkt - 1, std::true_type{});
 
     // ---- normalise and store: lane holds O[q][32 ht + (r & 3) + 8 (r >> 2) + 4 hh]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
