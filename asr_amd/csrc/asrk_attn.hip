@@ -31,18 +31,27 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 }
 
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                           int T, int H) {
+                                                           int T, int H, int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;   // half-wave
     const int l31 = lane & 31;
-    const int head = blockIdx.y, clip = blockIdx.z;
+    // Workgroup -> (clip, head, query block).  Blocks b and b + 8 run on the same XCD; all query blocks of one
+    // (clip, head) pair are given to ONE XCD, adjacent in launch order, so they walk the pair's K/V tiles together
+    // and every tile after the first reader's comes out of that XCD's L2.  (With query blocks dealt round-robin
+    // over the XCDs each XCD fetched its own copy: 2.5 GB of fabric reads per launch against 0.44 GB of q/k/v.)
+    const int nqb = (T + QT - 1) / QT;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pair = (j / nqb) * 8 + xcd;
+    if (pair >= n_pairs) return;
+    const int qb = j % nqb;
+    const int head = pair % H, clip = pair / H;
     const int d = H * HD;
     const int64_t ld = 3 * (int64_t)d;
     const bf16_t* base = qkv + (int64_t)clip * T * ld + head * HD;
-    const int q0 = blockIdx.x * QT + wave * 32;
+    const int q0 = qb * QT + wave * 32;
 
     // ---- Q^T fragments (MFMA B operand): lane holds Q[q0 + l31][16 s + 8 hh + 0..7]
     bf16x8 qf[4];
@@ -196,7 +205,10 @@ int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, h
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ASRK_ERR_ALIGN;
     const size_t lds = 4 * TILE_B;
     AsrkProfScope prof(ASRK_PROF_ATTENTION, 4.0 * B * H * (double)T * T * HD, st);
-    hipLaunchKernelGGL(attention_kernel, dim3((T + QT - 1) / QT, H, B), dim3(256), lds, st, qkv, out, T, H);
+    const long n_pairs = (long)B * H;
+    const long blocks = 8 * ((n_pairs + 7) / 8) * ((T + QT - 1) / QT);
+    if (blocks > 0x7fffffffL) return ASRK_ERR_SHAPE;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)blocks), dim3(256), lds, st, qkv, out, T, H, (int)n_pairs);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
 

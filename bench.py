@@ -131,6 +131,24 @@ def cpu_baseline(wname, w):
                 sample=f"{n} x 30 s clips x {reps} reps, oracle log-mel + fp32 encoder + projector (torch CPU, {cores} threads)")
 
 
+def pmc_traffic(workload, batch, kernel):
+    """HBM bytes per launch of the dominant kernel, from the PMC passes committed under profiles/
+    (tools/pmc_traffic.py; rocprofv3 cannot run inside this process).  None when no pass matches this
+    workload and batch."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if t.get("workload") != workload or t.get("clips_per_gpu") != batch:
+        return None
+    fam = {"gemm_bf16_kernel": "gemm", "attention_kernel": "attention", "layernorm_kernel": "layernorm",
+           "logmel_tile_kernel+logmel_finish_kernel": "logmel"}.get(kernel)
+    k = t.get("kernels", {}).get(fam)
+    return k["bytes_per_launch"] if k else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +247,8 @@ def main():
             roofline = dict(bound="hbm", kernel=names[dom], achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=ach / PEAK_HBM_GBS, traffic=None, avg_launch_us=ms * 1e3 / n, launches=n)
 
+    if rank == 0 and roofline is not None:
+        roofline["traffic"] = pmc_traffic(args.workload, B, roofline["kernel"])
     if rank == 0:
         value = world * B * 30.0 * args.steps / dt
         res = {
