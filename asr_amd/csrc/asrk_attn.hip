@@ -67,19 +67,37 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     const int srow = tid >> 3;  // + 32 * i
     const int slot = tid & 7;
     const int wave_lds = wave * 1024;
+    // source pointers of this thread's chunks in key tile 0; a tile further on is KT rows (tile_step elements) away.
+    // Only the ragged last tile needs its rows clamped, so only that one recomputes them.
+    const bf16_t* kp[2];
+    const bf16_t* vp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = srow + 32 * i;
+        const bf16_t* rp = base + (int64_t)(row < T ? row : T - 1) * ld;
+        kp[i] = rp + d + (slot ^ ((row >> 1) & 7)) * 8;            // K image: chunk ^ ((row >> 1) & 7)
+        vp[i] = rp + 2 * d + (slot ^ (((row >> 1) & 1) << 2)) * 8;  // V image: chunk ^ (((row >> 1) & 1) << 2)
+    }
+    const int64_t tile_step = (int64_t)KT * ld;
     auto stage = [&](int kt, int buf) {
         char* kb = smem + buf * (2 * TILE_B);
         char* vb = kb + TILE_B;
+        if ((kt + 1) * KT <= T) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = srow + 32 * i;
-            int kv = kt * KT + row;
-            kv = kv < T ? kv : T - 1;
-            const bf16_t* rp = base + (int64_t)kv * ld;
-            const int kc = slot ^ ((row >> 1) & 7);          // K image: chunk ^ ((row >> 1) & 7)
-            const int vc = slot ^ (((row >> 1) & 1) << 2);   // V image: chunk ^ (((row >> 1) & 1) << 2)
-            glds16(rp + d + kc * 8, kb + i * 4096 + wave_lds);
-            glds16(rp + 2 * d + vc * 8, vb + i * 4096 + wave_lds);
+            for (int i = 0; i < 2; ++i) {
+                glds16(kp[i] + kt * tile_step, kb + i * 4096 + wave_lds);
+                glds16(vp[i] + kt * tile_step, vb + i * 4096 + wave_lds);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = srow + 32 * i;
+                int kv = kt * KT + row;
+                kv = kv < T ? kv : T - 1;
+                const bf16_t* rp = base + (int64_t)kv * ld;
+                glds16(rp + d + (slot ^ ((row >> 1) & 7)) * 8, kb + i * 4096 + wave_lds);
+                glds16(rp + 2 * d + (slot ^ (((row >> 1) & 1) << 2)) * 8, vb + i * 4096 + wave_lds);
+            }
         }
     };
 
@@ -138,9 +156,20 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        // Lazy rescale: the running reference m_run only moves when the tile's maximum exceeds it by more than
+        // RESCALE_THR; until then p = exp(s - m_run) may reach e^THR (harmless in fp32 / bf16, whose exponent
+        // range is fp32's) and the 32 accumulator multiplies are skipped for the whole wave.  softmax is
+        // invariant to the reference, so the result differs from eager rescaling only in rounding.
+        constexpr float RESCALE_THR = 5.5f;
+        const bool moved = mx > m_run + RESCALE_THR;
+        const float m_new = moved ? mx : m_run;
         const float mb = m_new * LOG2E;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // wave-uniform
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
         float psum = 0.f;
         bf16x8 pf[2][2];  // [mt][k-step s]: registers 8 s .. 8 s + 7
 #pragma unroll
@@ -151,10 +180,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
                 psum += p;
                 pf[mt][r >> 3][r & 7] = (bf16_t)p;
             }
-        l_run = fmaf(l_run, alpha, psum);
+        l_run += psum;
         m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
 
         // ---- O^T[ht] += V^T[32 ht ..][keys] . P^T   (k order inside a step: 8 (j >> 2) + 4 hh + (j & 3))
 #pragma unroll
