@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the audio hot path on MI355X: log-mel -> encoder -> projector on 30 s clips.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload pipeline-small|pipeline-large|logmel]
+    python bench.py [--gpus N --steps K --warmup W] [--workload pipeline-small|pipeline-large|train-large|logmel]
 
 One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio that is already
 resident in HBM.  With N > 1 the driver launches one rank per GPU through torch.distributed.run;
@@ -14,6 +14,8 @@ Workloads (BASELINE.json configs):
                   projector 768 -> 960 -> 960, bf16 MFMA: configs[2] fed by the configs[1] front-end,
                   i.e. the metric's "log-mel+encoder+projector"
   pipeline-large  16 x 30 s per GPU, large-v3 dims (d1280 L32 H20 ffn5120, 128 mel)
+  train-large     configs[3]: pipeline-large plus projector backward (synthetic upstream gradient) and, for N > 1,
+                  one flat RCCL all-reduce of the projector gradients per step
   logmel          256 x 30 s per GPU, front-end only (configs[1]), HBM-bound
 """
 import argparse
@@ -35,6 +37,8 @@ PEAK_HBM_GBS = 8000.0      # HBM3E peak, same table
 WORKLOADS = {
     "pipeline-small": dict(batch=64, d_model=768, layers=12, heads=12, ffn=3072, n_mels=80, text_dim=960),
     "pipeline-large": dict(batch=16, d_model=1280, layers=32, heads=20, ffn=5120, n_mels=128, text_dim=960),
+    # BASELINE.json configs[3]: large-v3-class encoder forward + projector forward/backward + gradient all-reduce
+    "train-large": dict(batch=16, d_model=1280, layers=32, heads=20, ffn=5120, n_mels=128, text_dim=960, train=True),
     "logmel": dict(batch=256, n_mels=80),
 }
 
@@ -45,6 +49,8 @@ def flops_per_clip(w):
     stem = 2 * 3000 * d * 3 * C + 2 * 1500 * d * 3 * d
     layer = 2 * 1500 * (4 * d * d + 2 * d * F) + 4 * 1500 * 1500 * d
     proj = 2 * 1500 * (d * T + T * T)
+    if w.get("train"):  # projector backward: dW1, dW2 and dH through W2 (no dX into the frozen encoder)
+        proj += 2 * 1500 * (d * T + 2 * T * T)
     return stem + L * layer + proj
 
 
@@ -69,6 +75,8 @@ def seeded_models(w, device):
         if p.dim() >= 2 and "embed_positions" not in name:
             torch.nn.init.normal_(p, std=1.0 / np.sqrt(p.shape[1] * (p.shape[2] if p.dim() == 3 else 1)))
     proj = AudioProjector(w["d_model"], w["text_dim"], out_dtype=torch.bfloat16)
+    if not w.get("train"):
+        proj.requires_grad_(False)
     return enc.to(device), proj.to(device)
 
 
@@ -187,6 +195,26 @@ def main():
     if args.workload == "logmel":
         def step():
             return fe.extract_from_device(wave)
+    elif w.get("train"):
+        from asr_amd.distributed import FlatGradAllReducer
+
+        enc, proj = seeded_models(w, device)
+        reducer = FlatGradAllReducer(proj.parameters()) if dist is not None else None
+        # the decoder is outside this path: its gradient w.r.t. the audio embeddings is a fixed synthetic tensor
+        g_up = (torch.randn((B, 1500, w["text_dim"]), device=device) * 1e-2).to(torch.bfloat16)
+
+        def step():
+            feats = fe.extract_from_device(wave)
+            emb = proj(enc(feats))  # the encoder wrapper runs under no_grad (src/modeling.py:33-40)
+            if reducer is not None:
+                reducer.zero_()  # .grad tensors are views of the reducer's flat buffer
+            else:
+                for p_ in proj.parameters():
+                    p_.grad = None
+            emb.backward(g_up)
+            if reducer is not None:
+                reducer.all_reduce()
+            return emb.detach()
     else:
         enc, proj = seeded_models(w, device)
 

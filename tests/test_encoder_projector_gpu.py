@@ -74,6 +74,24 @@ def test_encoder_stem_and_layers_match_oracle():
         assert err <= REL
 
 
+def test_encoder_large_v3_dims_match_oracle():
+    """Whisper-large-v3 widths (d 1280, 20 heads, ffn 5120, 128 mel bins; BASELINE.json configs[3]) on two layers:
+    20 heads and K = 3 * 128 / 1280 / 5120 exercise tile counts the small-class cases do not.  Weights are too large
+    for a fixture, so both sides build them from the same seed and the checker is the CPU oracle (itself pinned
+    to HF by the tiny / mid / small fixtures)."""
+    from asr_amd.encoder import WhisperEncoder
+
+    d, layers, heads, ffn, n_mels = 1280, 2, 20, 5120, 128
+    sd = signals.encoder_state_dict(d, layers, ffn, n_mels, seed=21)
+    x = (signals.det_normal((1, n_mels, 3000), seed=77) * 0.5).astype(np.float32)
+    ref = oracle_encoder.encoder_forward(sd, x, heads, n_layers=layers).numpy()
+    enc = WhisperEncoder.from_state_dict(sd, n_heads=heads)
+    y = enc(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = rel_l2(y, ref)
+    print(f"large-v3 dims, {layers} layers: rel-L2 {err:.3e}")
+    assert y.shape == (1, 1500, d) and err <= REL
+
+
 def test_encoder_errors_and_batch_independence():
     enc, sd, c = build_encoder("tiny")
     with pytest.raises(ValueError, match="length 3000"):
