@@ -99,7 +99,7 @@ struct asrk_encoder {
 
 namespace {
 struct WsLayout {
-    size_t featT, h1, resid, xn, qkv, ao, ffn, total;
+    size_t featT, h1, resid, xn, qkv, ao, delta, ffn, total;
 };
 WsLayout ws_layout(const asrk_encoder_dims& d, int B) {
     WsLayout w;
@@ -112,6 +112,7 @@ WsLayout ws_layout(const asrk_encoder_dims& d, int B) {
     w.xn = take(M * d.d_model * 2);
     w.qkv = take(M * 3 * d.d_model * 2);
     w.ao = take(M * d.d_model * 2);
+    w.delta = take(M * d.d_model * 2);
     w.ffn = take(M * d.ffn_dim * 2);
     w.total = off;
     return w;
@@ -243,6 +244,7 @@ extern "C" int asrk_encoder_forward(const asrk_encoder* enc, const float* feats,
     bf16_t* xn = (bf16_t*)(w + wl.xn);
     bf16_t* qkv = (bf16_t*)(w + wl.qkv);
     bf16_t* ao = (bf16_t*)(w + wl.ao);
+    bf16_t* delta = (bf16_t*)(w + wl.delta);
     bf16_t* ffn = (bf16_t*)(w + wl.ffn);
     const int M = B * T_ENC;
     int rc;
@@ -284,14 +286,29 @@ extern "C" int asrk_encoder_forward(const asrk_encoder* enc, const float* feats,
         a.ldr = N; a.res_rows = M; a.alpha = 1.f; a.splits = 1;
         return asrk_gemm_launch(a, gelu, obf16, st);
     };
-    for (const LayerPacked& L : enc->layers) {
-        if ((rc = asrk_launch_layernorm(resid, L.ln1w, L.ln1b, xn, true, M, d, 1e-5f, st)) != ASRK_OK) return rc;
+    // The residual stream `resid` stays fp32.  The out-proj and fc2 GEMMs emit their result (bias included) as a
+    // bf16 delta, and the residual add x += delta is fused into the LayerNorm that follows it (ln2, the next
+    // layer's ln1, or the encoder's final norm): the add is exact in fp32, only the delta is rounded to bf16,
+    // like every other GEMM operand on this path.
+    const size_t nl = enc->layers.size();
+    if (nl == 0) return asrk_launch_layernorm(resid, enc->lnw, enc->lnb, out, false, M, d, 1e-5f, st);
+    if ((rc = asrk_launch_layernorm(resid, enc->layers[0].ln1w, enc->layers[0].ln1b, xn, true, M, d, 1e-5f, st)) != ASRK_OK)
+        return rc;
+    for (size_t i = 0; i < nl; ++i) {
+        const LayerPacked& L = enc->layers[i];
         if ((rc = linear(xn, d, L.wqkv, L.bqkv, 3 * d, qkv, false, true, nullptr)) != ASRK_OK) return rc;
         if ((rc = asrk_launch_attention(qkv, ao, B, T_ENC, H, st)) != ASRK_OK) return rc;
-        if ((rc = linear(ao, d, L.wo, L.bo, d, resid, false, false, resid)) != ASRK_OK) return rc;
-        if ((rc = asrk_launch_layernorm(resid, L.ln2w, L.ln2b, xn, true, M, d, 1e-5f, st)) != ASRK_OK) return rc;
+        if ((rc = linear(ao, d, L.wo, L.bo, d, delta, false, true, nullptr)) != ASRK_OK) return rc;
+        if ((rc = asrk_launch_add_layernorm(resid, delta, L.ln2w, L.ln2b, xn, true, true, M, d, 1e-5f, st)) != ASRK_OK) return rc;
         if ((rc = linear(xn, d, L.w1, L.b1, F, ffn, true, true, nullptr)) != ASRK_OK) return rc;
-        if ((rc = linear(ffn, F, L.w2, L.b2, d, resid, false, false, resid)) != ASRK_OK) return rc;
+        if ((rc = linear(ffn, F, L.w2, L.b2, d, delta, false, true, nullptr)) != ASRK_OK) return rc;
+        if (i + 1 < nl) {
+            const LayerPacked& Ln = enc->layers[i + 1];
+            rc = asrk_launch_add_layernorm(resid, delta, Ln.ln1w, Ln.ln1b, xn, true, true, M, d, 1e-5f, st);
+        } else {
+            rc = asrk_launch_add_layernorm(resid, delta, enc->lnw, enc->lnb, out, false, false, M, d, 1e-5f, st);
+        }
+        if (rc != ASRK_OK) return rc;
     }
-    return asrk_launch_layernorm(resid, enc->lnw, enc->lnb, out, false, M, d, 1e-5f, st);
+    return ASRK_OK;
 }

@@ -84,6 +84,8 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& a, f32x4 v, 
 // small helpers implemented in asrk_norm.hip
 int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* out, bool out_bf16, int M, int D,
                           float eps, hipStream_t st);
+int asrk_launch_add_layernorm(float* x, const bf16_t* delta, const float* w, const float* b, void* out, bool out_bf16,
+                              bool keep_x, int M, int D, float eps, hipStream_t st);
 int asrk_launch_rmsnorm_bf16(const float* x, const float* gamma, bf16_t* xn, float* rstd, int M, int D, float eps,
                              hipStream_t st);
 int asrk_launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, float scale, hipStream_t st);

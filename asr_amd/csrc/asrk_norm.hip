@@ -9,10 +9,14 @@ namespace {
 constexpr int MAX_V4 = 8;  // per-lane float4 chunks: D <= 64 * 4 * 8 = 2048
 
 // LayerNorm(x) * w + b, eps inside the sqrt (torch.nn.LayerNorm; HF modeling_whisper.py:392,402,642)
-template <bool OUT_BF16>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, void* __restrict__ out, int M,
-                                                        int D, float eps) {
+// ADD: the residual step is fused in front, x += delta (delta = the bf16 output of the out-proj / fc2 GEMM, bias
+// included; HF modeling_whisper.py:399,407), and the updated fp32 row is written back unless this is the
+// encoder's last norm (KEEP_X false).  The fp32 read-modify-write of the residual stream thereby runs in this
+// streaming kernel at >5 TB/s instead of in a GEMM epilogue, where every CU waits on it at once.
+template <bool OUT_BF16, bool ADD, bool KEEP_X>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* x, const bf16_t* __restrict__ delta,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        void* __restrict__ out, int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -25,6 +29,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * i;
         if (c < nv) {
             v[i] = xr[c];
+            if (ADD) {
+                const bf16x4 dv = reinterpret_cast<const bf16x4*>(delta + (size_t)row * D)[c];
+                v[i].x += (float)dv[0]; v[i].y += (float)dv[1]; v[i].z += (float)dv[2]; v[i].w += (float)dv[3];
+                if (KEEP_X) reinterpret_cast<float4*>(x + (size_t)row * D)[c] = v[i];
+            }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
@@ -118,10 +127,32 @@ int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* 
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)b & 15) || ((uintptr_t)out & 15)) return ASRK_ERR_ALIGN;
     const dim3 grid((M + 3) / 4);
     AsrkProfScope prof(ASRK_PROF_NORM, (double)M * D * (out_bf16 ? 6.0 : 8.0), st);
+    float* xm = const_cast<float*>(x);  // the plain variant never writes x
     if (out_bf16)
-        hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, w, b, out, M, D, eps);
+        hipLaunchKernelGGL((layernorm_kernel<true, false, false>), grid, dim3(256), 0, st, xm, nullptr, w, b, out, M, D, eps);
     else
-        hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, w, b, out, M, D, eps);
+        hipLaunchKernelGGL((layernorm_kernel<false, false, false>), grid, dim3(256), 0, st, xm, nullptr, w, b, out, M, D, eps);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+// x += delta (fp32 += bf16), then LayerNorm of the updated row.  keep_x false skips the write-back of x.
+int asrk_launch_add_layernorm(float* x, const bf16_t* delta, const float* w, const float* b, void* out, bool out_bf16,
+                              bool keep_x, int M, int D, float eps, hipStream_t st) {
+    if (!x || !delta || !w || !b || !out) return ASRK_ERR_NULL;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAX_V4) return ASRK_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)delta & 7) || ((uintptr_t)w & 15) || ((uintptr_t)b & 15) || ((uintptr_t)out & 15))
+        return ASRK_ERR_ALIGN;
+    const dim3 grid((M + 3) / 4);
+    // algorithmic bytes per element: x read 4 + delta read 2 + x write 4 (if kept) + output 2 or 4
+    AsrkProfScope prof(ASRK_PROF_NORM, (double)M * D * (6.0 + (keep_x ? 4.0 : 0.0) + (out_bf16 ? 2.0 : 4.0)), st);
+    if (out_bf16 && keep_x)
+        hipLaunchKernelGGL((layernorm_kernel<true, true, true>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+    else if (out_bf16)
+        hipLaunchKernelGGL((layernorm_kernel<true, true, false>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+    else if (keep_x)
+        hipLaunchKernelGGL((layernorm_kernel<false, true, true>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<false, true, false>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
 
