@@ -20,6 +20,8 @@
 #include "asrk_gemm.h"
 #include "asrk_prof.h"
 
+#include <cstdlib>
+
 #ifdef ASRK_STAMPS
 __device__ unsigned long long g_pstamps[1024 * 8];
 extern "C" int asrk_debug_read_pstamps(unsigned long long* host, int n) {
@@ -32,14 +34,16 @@ extern "C" int asrk_debug_read_pstamps(unsigned long long* host, int n) {
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64, NTHR = 512;
+// MT = 16-row accumulator blocks per wave: 8 -> 256-row tiles, 6 -> 192-row tiles.  The tile height is a launch-time
+// choice because the tile count rarely divides by the CU count (schedule_cost below); at the encoder's shapes the
+// 256-row tile wins everywhere, the 192-row tile only pays when the last round of 256-row tiles is nearly empty.
+constexpr int BN = 256, BK = 64, NTHR = 512;
 constexpr int RB = BK * 2;           // bytes per LDS row
 constexpr int CPR = RB / 16;         // 16-byte chunks per row
-constexpr int XOPER = BM * RB;       // bytes of the X slice
-constexpr int STAGE = XOPER + BN * RB;
-constexpr int GX = BM * CPR / NTHR, GW = BN * CPR / NTHR;
+constexpr int GW = BN * CPR / NTHR;
 constexpr int RPR = NTHR / CPR;      // rows staged per round of NTHR lanes
-constexpr int RING = 2 * STAGE;
+constexpr int STAGE_MAX = (256 + BN) * RB;
+constexpr int RING = 2 * STAGE_MAX;  // the ring is sized for the 256-row tile
 constexpr int PATCH = 4096;          // private epilogue patch per wave
 constexpr int LDS_BYTES = RING + 8 * PATCH;
 static_assert(LDS_BYTES == 163840, "uses all of the CU's LDS");
@@ -55,8 +59,8 @@ __device__ __forceinline__ void wave_lds_order() {
 }
 
 // One wave's 128 x 64 block (rows mw.., columns nw..) from accumulators to memory.
-template <bool GELU, bool OUT_BF16>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4][8], char* patch, int mw, int nw, int lane) {
+template <int MT, bool GELU, bool OUT_BF16>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4][MT], char* patch, int mw, int nw, int lane) {
     const int frow = lane & 15, fq = lane >> 4;
     f32x4 bv[4];
 #pragma unroll
@@ -71,7 +75,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
         int oq = (mw + r8) / a.o_rpb, orem = (mw + r8) % a.o_rpb;  // row map of the rows this lane stores, stepped by 8
         bf16_t* const out = reinterpret_cast<bf16_t*>(a.out) + a.o_off + nw + c8 * 8;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], mw + mt * 16 + frow, nw + nt * 16 + fq * 4);
@@ -115,8 +119,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
         };
         fetch(0, rv[0]);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            if (mt + 1 < 8) fetch(mt + 1, rv[(mt + 1) & 1]);
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt + 1 < MT) fetch(mt + 1, rv[(mt + 1) & 1]);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], mw + mt * 16 + frow, nw + nt * 16 + fq * 4);
@@ -137,8 +141,13 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
     }
 }
 
-template <bool GELU, bool OUT_BF16>
+template <int MT, bool GELU, bool OUT_BF16>
 __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
+    constexpr int BM = 32 * MT;          // 2 waves along m, 16 * MT rows each
+    constexpr int XOPER = BM * RB;       // bytes of the X slice
+    constexpr int STAGE = XOPER + BN * RB;
+    constexpr int GX = BM * CPR / NTHR;
+    static_assert(BM * CPR % NTHR == 0 && MT % 2 == 0, "tile height");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][X slice | W slice] | 8 epilogue patches
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -183,14 +192,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         for (int i = 0; i < GW; ++i) glds16(wp[i] + k0, sb + XOPER + i * (NTHR * 16) + wave_lds);
     };
 
-    f32x4 acc[4][8];  // [nt][mt]
+    f32x4 acc[4][MT];  // [nt][mt]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    const int x_off = (wm * 128 + frow) * RB;
+    const int x_off = (wm * (16 * MT) + frow) * RB;
     const int w_off = XOPER + (wn * 64 + frow) * RB;
     auto compute = [&](const char* sb) {
 #pragma unroll
@@ -201,16 +210,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
             for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(sb + w_off + t * 16 * RB + coff);
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh) {
-                bf16x8 xf[4];
+                constexpr int HB = MT / 2;
+                bf16x8 xf[HB];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    xf[t] = *reinterpret_cast<const bf16x8*>(sb + x_off + (mh * 4 + t) * 16 * RB + coff);
+                for (int t = 0; t < HB; ++t)
+                    xf[t] = *reinterpret_cast<const bf16x8*>(sb + x_off + (mh * HB + t) * 16 * RB + coff);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[nt][mh * 4 + t] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[t], acc[nt][mh * 4 + t], 0, 0, 0);
+                    for (int t = 0; t < HB; ++t)
+                        acc[nt][mh * HB + t] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[t], acc[nt][mh * HB + t], 0, 0, 0);
             }
         }
     };
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(2);
 #endif
-        epilogue_wave<GELU, OUT_BF16>(a, acc, smem + RING + wave * PATCH, m0 + wm * 128, n0 + wn * 64, lane);
+        epilogue_wave<MT, GELU, OUT_BF16>(a, acc, smem + RING + wave * PATCH, m0 + wm * (16 * MT), n0 + wn * 64, lane);
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(3); else if (tile_no == 1) PSTAMP(6);
         ++tile_no;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         t = tnext;
         m0 = m0n;
         n0 = n0n;
@@ -267,19 +277,36 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     PSTAMP(7);
 }
 
-template <bool GELU, bool OUT_BF16>
-int launch(const GemmArgs& a, hipStream_t st) {
+int device_cus() {
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 256;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 256;
         return n;
     }();
+    return cus;
+}
+
+// Time of the whole GEMM in units of "one 256-row tile on one CU": rounds of the fullest CU x relative tile cost.
+double schedule_cost(const GemmArgs& a, int mt) {
+    const int bm = 32 * mt;
+    const long tiles_m = (a.M + bm - 1) / bm, tiles_n = (a.N + BN - 1) / BN;
+    const long per_xcd = ((tiles_m + 7) / 8) * tiles_n;
+    const long wgs = device_cus() / 8;
+    const long rounds = (per_xcd + wgs - 1) / wgs;
+    // a 192-row tile does 3/4 of the MFMAs but loads the same W slice and pays the same barriers: measured 0.84 of a
+    // 256-row tile (fc2 at M = 96000: 6 rounds of 192 rows = 437 us against 5 rounds of 256 rows = 432 us)
+    return (double)rounds * (mt == 8 ? 1.0 : 0.84);
+}
+
+template <int MT, bool GELU, bool OUT_BF16>
+int launch(const GemmArgs& a, hipStream_t st) {
+    constexpr int BM = 32 * MT;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per_xcd = ((tiles_m + 7) / 8) * tiles_n;  // tiles of the fullest XCD
-    int wgs_per_xcd = cus / 8;
+    int wgs_per_xcd = device_cus() / 8;
     if (per_xcd < wgs_per_xcd) wgs_per_xcd = per_xcd;
-    auto kern = gemm256p_kernel<GELU, OUT_BF16>;
+    auto kern = gemm256p_kernel<MT, GELU, OUT_BF16>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
         return ASRK_ERR_HIP;
     AsrkProfScope prof(ASRK_PROF_GEMM, 2.0 * a.M * a.N * a.K, st);
@@ -287,11 +314,19 @@ int launch(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
 
+template <int MT>
+int dispatch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
+    if (gelu) return out_bf16 ? launch<MT, true, true>(a, st) : launch<MT, true, false>(a, st);
+    return out_bf16 ? launch<MT, false, true>(a, st) : launch<MT, false, false>(a, st);
+}
+
 }  // namespace
 
 // Arguments are validated by asrk_gemm_launch (asrk_gemm.hip); needs splits == 1, N % 8 == 0, K % 64 == 0.
 int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
     if (a.splits != 1 || (a.N % 8) != 0 || (a.K % BK) != 0) return ASRK_ERR_SHAPE;
-    if (gelu) return out_bf16 ? launch<true, true>(a, st) : launch<true, false>(a, st);
-    return out_bf16 ? launch<false, true>(a, st) : launch<false, false>(a, st);
+    // ASRK_GEMM_MT (A/B measurements only): 8 or 6 forces the tile height
+    static const int forced = [] { const char* e = getenv("ASRK_GEMM_MT"); return e ? atoi(e) : 0; }();
+    const bool use6 = forced == 6 || (forced != 8 && schedule_cost(a, 6) < schedule_cost(a, 8));
+    return use6 ? dispatch<6>(a, gelu, out_bf16, st) : dispatch<8>(a, gelu, out_bf16, st);
 }

@@ -21,6 +21,8 @@ SHAPES = {
     "fc1": (3072, 768, 1, 1, 1, 0),
     "fc1_nogelu": (3072, 768, 0, 1, 1, 0),
     "fc2": (768, 3072, 0, 0, 1, 1),
+    "out_bf16": (768, 768, 0, 1, 1, 0),     # the encoder's form since the residual add moved into LayerNorm
+    "fc2_bf16": (768, 3072, 0, 1, 1, 0),
     "sq4k": (4096, 4096, 0, 1, 0, 0),
 }
 
