@@ -180,3 +180,10 @@ extern "C" int asrk_layernorm(const float* x, const float* w, const float* b, vo
     if (out_dtype != ASRK_F32 && out_dtype != ASRK_BF16) return ASRK_ERR_UNSUPPORTED;
     return asrk_launch_layernorm(x, w, b, out, out_dtype == ASRK_BF16, M, D, eps, (hipStream_t)stream);
 }
+
+extern "C" int asrk_add_layernorm(float* x, const void* delta, const float* w, const float* b, void* out, int out_dtype,
+                                  int keep_x, int M, int D, float eps, void* stream) {
+    if (out_dtype != ASRK_F32 && out_dtype != ASRK_BF16) return ASRK_ERR_UNSUPPORTED;
+    return asrk_launch_add_layernorm(x, (const bf16_t*)delta, w, b, out, out_dtype == ASRK_BF16, keep_x != 0, M, D, eps,
+                                     (hipStream_t)stream);
+}

@@ -159,6 +159,12 @@ int asrk_gemm_bf16(const void* x, int64_t ldx, const void* w, const float* bias,
 int asrk_layernorm(const float* x, const float* w, const float* b, void* out, int out_dtype, int M, int D,
                    float eps, void* stream);
 
+/* The residual step fused in front of a LayerNorm: x[m][:] += delta[m][:] (fp32 += bf16; modeling_whisper.py:399,407),
+ * then out = LayerNorm(x) as above (:402, next layer's :392, or :642).  x is updated in place unless keep_x == 0
+ * (the encoder's last norm, whose input is not needed again).  delta bf16 [M][D] is the out-proj / fc2 result. */
+int asrk_add_layernorm(float* x, const void* delta, const float* w, const float* b, void* out, int out_dtype,
+                       int keep_x, int M, int D, float eps, void* stream);
+
 /* Bidirectional multi-head attention, head_dim 64, no mask, scaling 1.0 (q already scaled)
  * (modeling_whisper.py:215-238, 341-351).  qkv bf16 [B*T][3*H*64] (q | k | v per row),
  * out bf16 [B*T][H*64]. */

@@ -98,6 +98,28 @@ def test_layernorm(lib, M, D, out_bf16):
     assert err <= (4e-2 if out_bf16 else 2e-5), err
 
 
+@pytest.mark.parametrize("M,D", [(1, 128), (1500, 768), (333, 1280)])
+@pytest.mark.parametrize("out_bf16,keep_x", [(True, True), (False, False), (False, True)])
+def test_add_layernorm(lib, M, D, out_bf16, keep_x):
+    """x += delta (fp32 += bf16) fused in front of the LayerNorm; the fp32 sum is written back bit-exactly."""
+    g = torch.Generator(device="cuda").manual_seed(7 * M + D)
+    x = torch.randn((M, D), device="cuda", generator=g) * 3 + 1.5
+    delta = (torch.randn((M, D), device="cuda", generator=g) * 2).to(torch.bfloat16)
+    w = torch.randn((D,), device="cuda", generator=g)
+    b = torch.randn((D,), device="cuda", generator=g)
+    x_new = x + delta.float()
+    ref = torch.nn.functional.layer_norm(x_new, (D,), w, b, 1e-5)
+    xin = x.clone()
+    out = torch.empty((M, D), device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    rc = lib.asrk_add_layernorm(_p(xin), _p(delta), _p(w), _p(b), _p(out), int(out_bf16), int(keep_x), M, D, 1e-5, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(xin, x_new if keep_x else x)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= (4e-2 if out_bf16 else 2e-5), err
+    assert lib.asrk_add_layernorm(_p(xin), _p(None), _p(w), _p(b), _p(out), int(out_bf16), 1, M, D, 1e-5, _stream()) != 0
+
+
 @pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 128, 2), (1, 1500, 2), (2, 1500, 12), (1, 100, 3), (3, 257, 1)])
 def test_attention(lib, B, T, H):
     d = 64 * H
