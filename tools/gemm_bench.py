@@ -23,6 +23,8 @@ SHAPES = {
     "fc2": (768, 3072, 0, 0, 1, 1),
     "out_bf16": (768, 768, 0, 1, 1, 0),     # the encoder's form since the residual add moved into LayerNorm
     "fc2_bf16": (768, 3072, 0, 1, 1, 0),
+    "proj1": (960, 768, 1, 1, 1, 0),        # projector linear_1 + GELU, linear_2 (N = 960: ragged last n-tile)
+    "proj2": (960, 960, 0, 1, 1, 0),
     "sq4k": (4096, 4096, 0, 1, 0, 0),
 }
 
