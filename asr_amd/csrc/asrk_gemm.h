@@ -36,19 +36,27 @@ int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_
 // `bv` is the bias of those 4 columns, loaded once by the caller (it does not depend on the row: a load
 // per accumulator made the epilogue a chain of 32 dependent L2 round trips, 9.8 k cycles per tile).
 template <bool GELU>
-__device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v, f32x4 bv, int m, int n) {
+__device__ __forceinline__ f32x4 gemm_epilogue_value(float alpha, const bf16_t* dg_pre, int64_t ld_dg, bool in_range, f32x4 v,
+                                                     f32x4 bv, int m, int n) {
     v += bv;
     if (GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
     }
-    v *= a.alpha;
-    if (a.dg_pre && m < a.M && n < a.N) {
-        const bf16x4 pz = *reinterpret_cast<const bf16x4*>(a.dg_pre + (int64_t)m * a.ld_dg + n);
+    v *= alpha;
+    if (dg_pre && in_range) {
+        const bf16x4 pz = *reinterpret_cast<const bf16x4*>(dg_pre + (int64_t)m * ld_dg + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad((float)pz[j]);
     }
     return v;
+}
+// The same from the argument block.  Kernels whose epilogue is unrolled should read alpha / dg_pre / ld_dg into
+// locals once and call the form above: through the reference the compiler re-reads them from a scratch copy of
+// the kernel arguments at every call (32 scratch loads, each behind an s_waitcnt vmcnt(0), per 256 x 256 tile).
+template <bool GELU>
+__device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v, f32x4 bv, int m, int n) {
+    return gemm_epilogue_value<GELU>(a.alpha, a.dg_pre, a.ld_dg, m < a.M && n < a.N, v, bv, m, n);
 }
 
 // Shared epilogue: v = 4 consecutive n (n .. n+3) of output row m.  `orow` is the element offset

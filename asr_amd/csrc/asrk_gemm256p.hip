@@ -60,42 +60,58 @@ __device__ __forceinline__ void wave_lds_order() {
 
 // One wave's 128 x 64 block (rows mw.., columns nw..) from accumulators to memory.
 template <int MT, bool GELU, bool OUT_BF16>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4][MT], char* patch, int mw, int nw, int lane) {
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4][MT], float bias_lane, char* patch,
+                                              int mw, int nw, int lane) {
     const int frow = lane & 15, fq = lane >> 4;
+    // bias_lane = bias[nw + lane]; a lane needs columns nw + 16 nt + 4 fq .. +3
     f32x4 bv[4];
+    reinterpret_cast<float*>(patch)[lane] = bias_lane;
+    wave_lds_order();
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = nw + nt * 16 + fq * 4;
-        bv[nt] = (a.bias && n < a.N) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(patch + (nt * 16 + fq * 4) * 4);
+    wave_lds_order();
+    const float alpha = a.alpha;  // locals, not a.*: see gemm_epilogue_value
+    const bf16_t* const dg_pre = a.dg_pre;
+    const int64_t ld_dg = a.ld_dg;
+    const int M = a.M, N = a.N;
     if (OUT_BF16) {
-        constexpr int ROWB = 144;  // 128 B of data + 16 B pad
+        // Two [16][64] bf16 half-patches (2 KiB each), used alternately so the stores of one 16-row group overlap
+        // the staging of the next.  8-byte unit u of row r lives at unit u ^ r: conflict-free for the
+        // accumulator-layout ds_write_b64 (16 rows x one unit) and for the row-layout ds_read_b128 (a 16-byte
+        // chunk is the unit pair 2c, 2c+1 -> pair c ^ (r >> 1), halves swapped when r is odd).
         const int r8 = lane >> 3, c8 = lane & 7;
         const bool col_ok = nw + c8 * 8 < a.N;
         int oq = (mw + r8) / a.o_rpb, orem = (mw + r8) % a.o_rpb;  // row map of the rows this lane stores, stepped by 8
         bf16_t* const out = reinterpret_cast<bf16_t*>(a.out) + a.o_off + nw + c8 * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            char* half = patch + (mt & 1) * 2048;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], mw + mt * 16 + frow, nw + nt * 16 + fq * 4);
+                const int m = mw + mt * 16 + frow, n = nw + nt * 16 + fq * 4;
+                const f32x4 v = gemm_epilogue_value<GELU>(alpha, dg_pre, ld_dg, m < M && n < N, acc[nt][mt], bv[nt], m, n);
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-                *reinterpret_cast<bf16x4*>(patch + frow * ROWB + (nt * 16 + fq * 4) * 2) = o;
+                *reinterpret_cast<bf16x4*>(half + frow * 128 + (((nt * 4 + fq) ^ frow) << 3)) = o;
             }
             wave_lds_order();
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int row = h * 8 + r8;
-                const uint4 v = *reinterpret_cast<const uint4*>(patch + row * ROWB + c8 * 16);
+                uint4 v = *reinterpret_cast<const uint4*>(half + row * 128 + ((c8 ^ (row >> 1)) << 4));
+                if (row & 1) v = uint4{v.z, v.w, v.x, v.y};
+#ifdef ASRK_NOSTORE  // diagnostic: epilogue cost without its global stores (a never-true condition keeps the data path)
+                if (col_ok && mw + mt * 16 + row < a.M && v.x == 0x7fc07fc1u && v.y == 0x12345678u)
+#else
                 if (col_ok && mw + mt * 16 + row < a.M)
+#endif
                     *reinterpret_cast<uint4*>(out + (int64_t)oq * a.o_bs + (int64_t)orem * a.o_rs) = v;
                 orem += 8;
                 while (orem >= a.o_rpb) { orem -= a.o_rpb; ++oq; }
             }
-            wave_lds_order();
         }
+        wave_lds_order();
     } else {
         // [16][64] fp32 patch, exactly 4 KiB: 16-byte chunk c of row r lives at chunk c ^ r (conflict-free for
         // the accumulator-layout ds_write_b128 and for the row-layout ds_read_b128)
@@ -123,7 +139,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
             if (mt + 1 < MT) fetch(mt + 1, rv[(mt + 1) & 1]);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], mw + mt * 16 + frow, nw + nt * 16 + fq * 4);
+                const int m = mw + mt * 16 + frow, n = nw + nt * 16 + fq * 4;
+                const f32x4 v = gemm_epilogue_value<GELU>(alpha, dg_pre, ld_dg, m < M && n < N, acc[nt][mt], bv[nt], m, n);
                 *reinterpret_cast<f32x4*>(patch + frow * 256 + (((nt * 4 + fq) ^ frow) << 4)) = v;
             }
             wave_lds_order();
@@ -226,9 +243,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     };
 
     const int nkt = a.K / BK;
+    float bias_lane = 0.f;
     int t = lidx;
     int m0 = (tm_lo + t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
     set_sources(m0, n0);
+    // start-up phase skew (ASRK_GEMM_SKEW, measurements): spread the workgroups' tile phases so that the epilogue
+    // stores of some CUs run under the K loops of the others instead of all at once
+    if (a.skew > 0) {
+        const int n = ((blockIdx.x >> 3) & 7) * a.skew;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     PSTAMP(0);
     stage(0, 0);
     int slot = 0;
@@ -248,7 +272,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
 #endif
             if (kt + 1 < nkt) {
                 stage(kt + 1, slot ^ 1);
-            } else if (has_next) {  // the K stream runs on into the next tile
+            } else {
+                // this tile's bias, one column per lane (spread to the accumulator layout through the LDS patch in
+                // the epilogue).  Issued BEFORE the next tile's first global_load_lds: loads return in order, so
+                // the epilogue waits for it with those 8 still in flight instead of draining them.
+                const int n = n0 + wn * 64 + lane;
+                bias_lane = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+            }
+            if (kt + 1 == nkt && has_next) {  // the K stream runs on into the next tile
                 m0n = (tm_lo + tnext / tiles_n) * BM;
                 n0n = (tnext % tiles_n) * BN;
                 set_sources(m0n, n0n);
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(2);
 #endif
-        epilogue_wave<MT, GELU, OUT_BF16>(a, acc, smem + RING + wave * PATCH, m0 + wm * (16 * MT), n0 + wn * 64, lane);
+        epilogue_wave<MT, GELU, OUT_BF16>(a, acc, bias_lane, smem + RING + wave * PATCH, m0 + wm * (16 * MT), n0 + wn * 64, lane);
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(3); else if (tile_no == 1) PSTAMP(6);
         ++tile_no;
@@ -300,7 +331,10 @@ double schedule_cost(const GemmArgs& a, int mt) {
 }
 
 template <int MT, bool GELU, bool OUT_BF16>
-int launch(const GemmArgs& a, hipStream_t st) {
+int launch(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    static const int skew = [] { const char* e = getenv("ASRK_GEMM_SKEW"); return e ? atoi(e) : 0; }();
+    a.skew = skew;
     constexpr int BM = 32 * MT;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per_xcd = ((tiles_m + 7) / 8) * tiles_n;  // tiles of the fullest XCD
