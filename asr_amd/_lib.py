@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasrk.so")
+# ASRK_LIB_PATH: A/B measurements of two builds inside one GPU call (device-to-device spread is 1-3 %)
+LIB_PATH = os.environ.get("ASRK_LIB_PATH") or os.path.join(_HERE, "libasrk.so")
 
 ASRK_F32, ASRK_BF16 = 0, 1
 

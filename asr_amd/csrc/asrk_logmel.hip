@@ -56,6 +56,13 @@ __global__ __launch_bounds__(NTHREADS) void logmel_tile_kernel(const float* __re
 
     // ---- stage the tile's samples (center=True, reflect padding; torch.stft semantics)
     const int s0 = t0 * HOP - NFFT / 2;
+    // interior tiles (no reflection, 16-byte aligned: t0 is a multiple of 32, so s0 is a multiple of 4 samples)
+    // copy with 16-byte loads; only a clip's first and last tiles take the indexed path
+    const bool interior = s0 >= 0 && s0 + TILE_S <= n_samples && ((n_samples & 3) == 0) && ((reinterpret_cast<uintptr_t>(wave) & 15) == 0);
+    if (interior) {
+        const float4* src = reinterpret_cast<const float4*>(x + s0);
+        for (int i = tid; i < TILE_S / 4; i += NTHREADS) reinterpret_cast<float4*>(S)[i] = src[i];
+    } else
     for (int i = tid; i < TILE_S; i += NTHREADS) {
         int s = s0 + i;
         if (s < 0) s = -s;
@@ -89,7 +96,9 @@ __global__ __launch_bounds__(NTHREADS) void logmel_tile_kernel(const float* __re
         const int b0 = Lstart[m], p0 = Lptr[m], p1 = Lptr[m + 1];
         float acc = 0.f;
         for (int q = p0; q < p1; ++q) acc = fmaf(Lw[q], prow[b0 + q - p0], acc);
-        const float v = acc > 1e-10f ? log10f(acc) : -10.0f;  // clamp(min=1e-10).log10(): silence is exactly -10
+        // clamp(min=1e-10).log10(): silence is exactly -10.  v_log_f32 (log2, 1 ulp) * log10(2): |err| < 2e-6 here,
+        // against ~25 instructions for log10f()
+        const float v = acc > 1e-10f ? __builtin_amdgcn_logf(acc) * 0.30102999566398120f : -10.0f;
         if (valid) {
             obase[(size_t)m * n_frames] = v;
             vmax = fmaxf(vmax, v);

@@ -35,8 +35,6 @@ def main():
     ap.add_argument("--M", type=int, default=96000)
     ap.add_argument("--shapes", default="qkv,out,fc1,fc1_nogelu,fc2")
     args = ap.parse_args()
-    if os.environ.get("ASRK_BENCH_LIB"):  # A/B two builds inside one GPU call (device-to-device spread is 1-3 %)
-        _lib.LIB_PATH = os.path.abspath(os.environ["ASRK_BENCH_LIB"])
     lib = _lib.load()
     p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
