@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--workload", default="pipeline-small", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-input", action="store_true",
+                    help="diagnostic: each step starts from pinned host memory (adds the H2D copy of the padded waveforms; "
+                         "the contract's `value` is measured WITHOUT this flag, inputs resident in HBM)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,9 +195,19 @@ def main():
     B = w["batch"]
     fe = LogMelFeatureExtractor(feature_size=w["n_mels"])
     wave = synth_audio(B, rank, device)
+    if args.host_input:
+        wave_host = wave.cpu().pin_memory()
+        wave_dev = wave
+
+        def fetch():
+            wave_dev.copy_(wave_host, non_blocking=True)
+            return wave_dev
+    else:
+        def fetch():
+            return wave
     if args.workload == "logmel":
         def step():
-            return fe.extract_from_device(wave)
+            return fe.extract_from_device(fetch())
     elif w.get("train"):
         from asr_amd.distributed import FlatGradAllReducer
 
@@ -204,7 +217,7 @@ def main():
         g_up = (torch.randn((B, 1500, w["text_dim"]), device=device) * 1e-2).to(torch.bfloat16)
 
         def step():
-            feats = fe.extract_from_device(wave)
+            feats = fe.extract_from_device(fetch())
             emb = proj(enc(feats))  # the encoder wrapper runs under no_grad (src/modeling.py:33-40)
             if reducer is not None:
                 reducer.zero_()  # .grad tensors are views of the reducer's flat buffer
@@ -220,7 +233,7 @@ def main():
 
         def step():
             with torch.no_grad():
-                feats = fe.extract_from_device(wave)
+                feats = fe.extract_from_device(fetch())
                 return proj(enc(feats))
 
     def barrier():
@@ -288,6 +301,8 @@ def main():
                        "parallelism": f"dp{world} (independent clips, no data-path collective)"},
             "roofline": roofline, "stages": stages,
         }
+        if args.host_input:
+            res["data"] = "synthetic, copied from pinned host memory every step (diagnostic, not the contract's value)"
         if args.workload != "logmel":
             fl = flops_per_clip(w)
             res["pipeline_tflops"] = fl * world * B * args.steps / dt / 1e12
