@@ -30,6 +30,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
     return __builtin_bit_cast(bf16x4, r);
 }
 
+// LOG2Q: q arrives multiplied by log2(e) as well (the encoder folds it into W_q and b_q), so scores are in log2
+// units and p = 2^(s - ref).  The reference is then subtracted by the MFMA itself: the score accumulators start
+// from -ref (a 16-register block that changes only when the reference moves) instead of 0, and the per-score
+// multiply-subtract in front of every v_exp_f32 disappears (31 of ~170 vector instructions per key tile).
+template <bool LOG2Q>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int T, int H, int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
@@ -107,6 +112,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = -1e30f, l_run = 0.f;
+    float nref = 0.f;        // LOG2Q: minus the softmax reference of this lane's query ...
+    f32x16 negm;             // ... and the same value in the 16 registers the score MFMAs start from
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
     constexpr float LOG2E = 1.4426950408889634f;
 
     // fragment read offsets
@@ -132,8 +141,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         f32x16 sacc[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            if (LOG2Q) {
+                sacc[mt] = negm;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[mt][i] = 0.f;
+                for (int i = 0; i < 16; ++i) sacc[mt][i] = 0.f;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + mt * 4096 + k_row_off + (((2 * s + hh) ^ k_sw) << 4));
@@ -156,32 +169,59 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // Lazy rescale: the running reference m_run only moves when the tile's maximum exceeds it by more than
-        // RESCALE_THR; until then p = exp(s - m_run) may reach e^THR (harmless in fp32 / bf16, whose exponent
-        // range is fp32's) and the 32 accumulator multiplies are skipped for the whole wave.  softmax is
-        // invariant to the reference, so the result differs from eager rescaling only in rounding.
-        constexpr float RESCALE_THR = 5.5f;
-        const bool moved = mx > m_run + RESCALE_THR;
-        const float m_new = moved ? mx : m_run;
-        const float mb = m_new * LOG2E;
-        if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // wave-uniform
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-        }
+        // Lazy rescale: the running reference only moves when the tile's maximum exceeds it by more than
+        // RESCALE_THR; until then p may reach e^THR (harmless in fp32 / bf16, whose exponent range is fp32's)
+        // and the 32 accumulator multiplies are skipped for the whole wave.  softmax is invariant to the
+        // reference, so the result differs from eager rescaling only in rounding.
         float psum = 0.f;
         bf16x8 pf[2][2];  // [mt][k-step s]: registers 8 s .. 8 s + 7
+        if (LOG2Q) {
+            // sacc already holds s - ref (log2 units); the first tile always sets the reference to its maximum
+            constexpr float THR2 = 8.0f;
+            const bool moved = kt == 0 || mx > THR2;
+            if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // wave-uniform
+                const float dlt = moved ? mx : 0.f;
+                const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-dlt);
+                l_run *= alpha;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+                for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[mt][r], LOG2E, -mb));  // bare v_exp_f32: exp2f() adds a denormal-range rescale (5 VALU) per call
-                psum += p;
-                pf[mt][r >> 3][r & 7] = (bf16_t)p;
+                for (int i = 0; i < 16; ++i) { sacc[0][i] -= dlt; sacc[1][i] -= dlt; }
+                nref -= dlt;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) negm[i] = nref;
             }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[mt][r]);
+                    psum += p;
+                    pf[mt][r >> 3][r & 7] = (bf16_t)p;
+                }
+        } else {
+            constexpr float RESCALE_THR = 5.5f;
+            const bool moved = mx > m_run + RESCALE_THR;
+            const float m_new = moved ? mx : m_run;
+            const float mb = m_new * LOG2E;
+            if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // wave-uniform
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // bare v_exp_f32: exp2f() adds a denormal-range rescale (5 VALU) per call
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[mt][r], LOG2E, -mb));
+                    psum += p;
+                    pf[mt][r >> 3][r & 7] = (bf16_t)p;
+                }
+            m_run = m_new;
+        }
         l_run += psum;
-        m_run = m_new;
 
         // ---- O^T[ht] += V^T[32 ht ..][keys] . P^T   (k order inside a step: 8 (j >> 2) + 4 hh + (j & 3))
 #pragma unroll
@@ -226,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 
 }  // namespace
 
-int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, hipStream_t st) {
+int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, bool q_log2e, hipStream_t st) {
     if (!qkv || !out) return ASRK_ERR_NULL;
     if (B <= 0 || T <= 0 || H <= 0 || H > 65535 || B > 65535) return ASRK_ERR_SHAPE;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15)) return ASRK_ERR_ALIGN;
@@ -235,10 +275,13 @@ int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, h
     const long n_pairs = (long)B * H;
     const long blocks = 8 * ((n_pairs + 7) / 8) * ((T + QT - 1) / QT);
     if (blocks > 0x7fffffffL) return ASRK_ERR_SHAPE;
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)blocks), dim3(256), lds, st, qkv, out, T, H, (int)n_pairs);
+    if (q_log2e)
+        hipLaunchKernelGGL(attention_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, qkv, out, T, H, (int)n_pairs);
+    else
+        hipLaunchKernelGGL(attention_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, qkv, out, T, H, (int)n_pairs);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
 
 extern "C" int asrk_attention_bf16(const void* qkv, void* out, int B, int T, int H, void* stream) {
-    return asrk_launch_attention((const bf16_t*)qkv, (bf16_t*)out, B, T, H, (hipStream_t)stream);
+    return asrk_launch_attention((const bf16_t*)qkv, (bf16_t*)out, B, T, H, false, (hipStream_t)stream);
 }

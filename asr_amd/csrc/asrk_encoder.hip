@@ -173,7 +173,9 @@ extern "C" int asrk_encoder_create(const asrk_encoder_dims* dims, const asrk_enc
     copyf(w->pos, o_pos, T_ENC * d, 1.f);
     copyf(w->ln_w, o_lnw, d, 1.f);
     copyf(w->ln_b, o_lnb, d, 1.f);
-    const float qscale = 0.125f;  // head_dim^-0.5 for head_dim 64, applied to q_proj output (:309)
+    // head_dim^-0.5 for head_dim 64, applied to q_proj output (:309), times log2(e): the attention kernel works in
+    // log2 units (asrk_launch_attention, q_log2e)
+    const float qscale = 0.125f * 1.4426950408889634f;
     for (int i = 0; i < L && rc == ASRK_OK; ++i) {
         const asrk_encoder_layer_weights& lw = w->layers[i];
         castw(lw.q_w, lo[i].wqkv, (size_t)d * d, qscale);
@@ -297,7 +299,7 @@ extern "C" int asrk_encoder_forward(const asrk_encoder* enc, const float* feats,
     for (size_t i = 0; i < nl; ++i) {
         const LayerPacked& L = enc->layers[i];
         if ((rc = linear(xn, d, L.wqkv, L.bqkv, 3 * d, qkv, false, true, nullptr)) != ASRK_OK) return rc;
-        if ((rc = asrk_launch_attention(qkv, ao, B, T_ENC, H, st)) != ASRK_OK) return rc;
+        if ((rc = asrk_launch_attention(qkv, ao, B, T_ENC, H, true, st)) != ASRK_OK) return rc;
         if ((rc = linear(ao, d, L.wo, L.bo, d, delta, false, true, nullptr)) != ASRK_OK) return rc;
         if ((rc = asrk_launch_add_layernorm(resid, delta, L.ln2w, L.ln2b, xn, true, true, M, d, 1e-5f, st)) != ASRK_OK) return rc;
         if ((rc = linear(xn, d, L.w1, L.b1, F, ffn, true, true, nullptr)) != ASRK_OK) return rc;

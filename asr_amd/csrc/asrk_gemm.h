@@ -97,4 +97,5 @@ int asrk_launch_add_layernorm(float* x, const bf16_t* delta, const float* w, con
 int asrk_launch_rmsnorm_bf16(const float* x, const float* gamma, bf16_t* xn, float* rstd, int M, int D, float eps,
                              hipStream_t st);
 int asrk_launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, float scale, hipStream_t st);
-int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, hipStream_t st);
+// q_log2e: q carries an extra factor log2(e) (folded into W_q / b_q by the caller)
+int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, bool q_log2e, hipStream_t st);
