@@ -68,6 +68,10 @@ _SIGNATURES = {
     "asrk_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "asrk_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "asrk_find_token_i64": (c_int, [c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
+    "asrk_embed_splice": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "asrk_embed_splice_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asrk_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p]),
     "asrk_attention_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -165,6 +165,22 @@ int asrk_layernorm(const float* x, const float* w, const float* b, void* out, in
 int asrk_add_layernorm(float* x, const void* delta, const float* w, const float* b, void* out, int out_dtype,
                        int keep_x, int M, int D, float eps, void* stream);
 
+/* ---- audio-embedding splice (src/modeling.py:222-276) ------------------------------
+ * first_idx[b] = index of the first `token` in ids[b][0..L), -1 if absent (the reference's
+ * (input_ids[i] == audio_chunk_id).nonzero()[0], :223-227, without its per-sample host sync). */
+int asrk_find_token_i64(const int64_t* ids, int B, int L, int64_t token, int* first_idx, void* stream);
+
+/* out_embeds[b] = cat(text[b][:c], audio[b], text[b][c+1:]) with c = chunk_idx[b] (:229-237), [B][L-1+A][D];
+ * out_labels[b] = cat(labels[b][:c], -100 x A, labels[b][c+1:]) (:239-245) and out_mask = 1 (:266; all rows have the
+ * same length, the reference's padding branch never pads) -- both optional.  dtype ASRK_BF16 | ASRK_F32, D * size % 16 == 0. */
+int asrk_embed_splice(const void* text, const void* audio, const int* chunk_idx, const int64_t* labels, int B, int L, int A,
+                      int D, int dtype, void* out_embeds, int64_t* out_labels, int64_t* out_mask, void* stream);
+
+/* Adjoint of asrk_embed_splice (autograd of torch.cat, :229-237): rows of grad_out go back to grad_audio [B][A][D] and
+ * grad_text [B][L][D] (row c, the dropped placeholder, is zeroed).  Either output may be NULL. */
+int asrk_embed_splice_backward(const void* grad_out, const int* chunk_idx, int B, int L, int A, int D, int dtype,
+                               void* grad_text, void* grad_audio, void* stream);
+
 /* Bidirectional multi-head attention, head_dim 64, no mask, scaling 1.0 (q already scaled)
  * (modeling_whisper.py:215-238, 341-351).  qkv bf16 [B*T][3*H*64] (q | k | v per row),
  * out bf16 [B*T][H*64]. */
