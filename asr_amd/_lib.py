@@ -79,7 +79,7 @@ _SIGNATURES = {
     "asrk_profile_read": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_int]),
 }
 
-PROF_GEMM, PROF_ATTENTION, PROF_LOGMEL, PROF_NORM = 0, 1, 2, 3
+PROF_GEMM, PROF_ATTENTION, PROF_LOGMEL, PROF_NORM, PROF_SPLICE = 0, 1, 2, 3, 4
 
 
 def profile_read(cat: int, reset: bool = True):

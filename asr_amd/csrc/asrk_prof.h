@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { ASRK_PROF_GEMM = 0, ASRK_PROF_ATTENTION = 1, ASRK_PROF_LOGMEL = 2, ASRK_PROF_NORM = 3 };
+enum { ASRK_PROF_GEMM = 0, ASRK_PROF_ATTENTION = 1, ASRK_PROF_LOGMEL = 2, ASRK_PROF_NORM = 3, ASRK_PROF_SPLICE = 4 };
 
 bool asrk_prof_enabled();
 int asrk_prof_begin(int cat, double work, hipStream_t st);

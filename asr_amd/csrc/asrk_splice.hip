@@ -106,6 +106,9 @@ extern "C" int asrk_embed_splice(const void* text, const void* audio, const int*
     if (B <= 0 || L <= 0 || A <= 0 || D <= 0 || B > 65535 || ((size_t)D * eb) % 16) return ASRK_ERR_SHAPE;
     if (((uintptr_t)text & 15) || ((uintptr_t)audio & 15) || ((uintptr_t)out_embeds & 15)) return ASRK_ERR_ALIGN;
     const int T = L - 1 + A;
+    // algorithmic bytes: every output row is read once and written once (+ labels / mask, 8 bytes each per position)
+    AsrkProfScope prof(ASRK_PROF_SPLICE, 2.0 * B * T * D * eb + (out_labels ? 16.0 : 0.0) * B * T + (out_mask ? 8.0 : 0.0) * B * T,
+                       (hipStream_t)stream);
     hipLaunchKernelGGL(splice_fwd_kernel, dim3((T + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, (const char*)text,
                        (const char*)audio, chunk_idx, (const long long*)labels, L, A, D * eb, (char*)out_embeds,
                        (long long*)out_labels, (long long*)out_mask);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the audio hot path on MI355X: log-mel -> encoder -> projector on 30 s clips.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload pipeline-small|pipeline-large|train-large|logmel]
+    python bench.py [--gpus N --steps K --warmup W] [--workload pipeline-small|pipeline-large|train-large|logmel|splice]
 
 One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio that is already
 resident in HBM.  With N > 1 the driver launches one rank per GPU through torch.distributed.run;
@@ -17,6 +17,7 @@ Workloads (BASELINE.json configs):
   train-large     configs[3]: pipeline-large plus projector backward (synthetic upstream gradient) and, for N > 1,
                   one flat RCCL all-reduce of the projector gradients per step
   logmel          256 x 30 s per GPU, front-end only (configs[1]), HBM-bound
+  splice          SURVEY 8(f2): the embed splice of ASRModel.forward alone, 64 samples (HBM-bound copy)
 """
 import argparse
 import json
@@ -40,6 +41,9 @@ WORKLOADS = {
     # BASELINE.json configs[3]: large-v3-class encoder forward + projector forward/backward + gradient all-reduce
     "train-large": dict(batch=16, d_model=1280, layers=32, heads=20, ffn=5120, n_mels=128, text_dim=960, train=True),
     "logmel": dict(batch=256, n_mels=80),
+    # the embed splice of ASRModel.forward, 64 samples x (64 text tokens + 1500 audio
+    # positions) x 960 (SmolLM2-360M width), bf16 like the decoder; HBM-bound copy
+    "splice": dict(batch=64, text_len=64, text_dim=960),
 }
 
 
@@ -89,6 +93,22 @@ def cpu_baseline(wname, w):
 
     cores = torch.get_num_threads()
     rng = np.random.default_rng(1234)
+    if wname == "splice":
+        from oracle import splice as osp
+
+        n, Lt, D = 16, w["text_len"], w["text_dim"]
+        text = rng.standard_normal((n, Lt, D)).astype(np.float32)
+        audio = rng.standard_normal((n, 1500, D)).astype(np.float32)
+        ids = rng.integers(0, 49000, size=(n, Lt), dtype=np.int64)
+        ids[:, 5] = 49153
+        labels = rng.integers(0, 49000, size=(n, Lt), dtype=np.int64)
+        osp.splice(text, audio, ids, labels, 49153)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            osp.splice(text, audio, ids, labels, 49153)
+        dt = (time.perf_counter() - t0) / 5
+        return dict(value=n * 30.0 / dt, unit="audio-sec/sec", cores=1, kind="port",
+                    sample=f"{n} samples x 5 reps, NumPy oracle splice (fp32, single thread)")
     if wname == "logmel":
         n = 8
         wave = np.clip(0.1 * rng.standard_normal((n, 480000), dtype=np.float32), -1, 1)
@@ -193,7 +213,7 @@ def main():
     if args.batch:
         w["batch"] = args.batch
     B = w["batch"]
-    fe = LogMelFeatureExtractor(feature_size=w["n_mels"])
+    fe = LogMelFeatureExtractor(feature_size=w.get("n_mels", 80))
     wave = synth_audio(B, rank, device)
     if args.host_input:
         wave_host = wave.cpu().pin_memory()
@@ -205,7 +225,20 @@ def main():
     else:
         def fetch():
             return wave
-    if args.workload == "logmel":
+    if args.workload == "splice":
+        from asr_amd.splice import splice_audio_embeddings
+
+        g = torch.Generator(device=device).manual_seed(rank)
+        Ltxt, Dtxt, chunk_id = w["text_len"], w["text_dim"], 49153
+        text = torch.randn((B, Ltxt, Dtxt), device=device, generator=g).to(torch.bfloat16)
+        audio = torch.randn((B, 1500, Dtxt), device=device, generator=g).to(torch.bfloat16)
+        ids = torch.randint(0, 49000, (B, Ltxt), device=device, generator=g)
+        ids[:, 5] = chunk_id
+        labels = torch.randint(0, 49000, (B, Ltxt), device=device, generator=g)
+
+        def step():
+            return splice_audio_embeddings(text, audio, ids, labels, chunk_id)[0]
+    elif args.workload == "logmel":
         def step():
             return fe.extract_from_device(fetch())
     elif w.get("train"):
@@ -266,7 +299,8 @@ def main():
         torch.cuda.synchronize()
         lib.asrk_profile_enable(0)
         names = {_lib.PROF_GEMM: "gemm_bf16_kernel", _lib.PROF_ATTENTION: "attention_kernel",
-                 _lib.PROF_LOGMEL: "logmel_tile_kernel+logmel_finish_kernel", _lib.PROF_NORM: "layernorm_kernel"}
+                 _lib.PROF_LOGMEL: "logmel_tile_kernel+logmel_finish_kernel", _lib.PROF_NORM: "layernorm_kernel",
+                 _lib.PROF_SPLICE: "splice_fwd_kernel"}
         tot = {}
         for cat, nm in names.items():
             ms, work, n = _lib.profile_read(cat)
@@ -303,7 +337,7 @@ def main():
         }
         if args.host_input:
             res["data"] = "synthetic, copied from pinned host memory every step (diagnostic, not the contract's value)"
-        if args.workload != "logmel":
+        if args.workload not in ("logmel", "splice"):
             fl = flops_per_clip(w)
             res["pipeline_tflops"] = fl * world * B * args.steps / dt / 1e12
             res["flops_per_clip"] = fl

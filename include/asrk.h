@@ -190,7 +190,7 @@ int asrk_attention_bf16(const void* qkv, void* out, int B, int T, int H, void* s
  * Measurement hook (no counterpart in the reference, which has no profiler: SURVEY section 5).
  * When enabled, every GEMM / attention / log-mel / LayerNorm launch is bracketed by HIP events on
  * its own stream; asrk_profile_read sums one category (0 GEMM: work = 2MNK flops, 1 attention:
- * 4*B*H*T*T*64 flops, 2 log-mel: algorithmic bytes, 3 LayerNorm: bytes) after the caller has
+ * 4*B*H*T*T*64 flops, 2 log-mel: algorithmic bytes, 3 LayerNorm: bytes, 4 embed splice: bytes) after the caller has
  * synchronised.  bench.py uses it for the `roofline` object.  Off by default.
  * ---------------------------------------------------------------------------------------- */
 int asrk_profile_enable(int on);
