@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ASRK_LIB_PATH: A/B measurements of two builds inside one GPU call (device-to-device spread is 1-3 %)
 LIB_PATH = os.environ.get("ASRK_LIB_PATH") or os.path.join(_HERE, "libasrk.so")
 
-ASRK_F32, ASRK_BF16 = 0, 1
+ASRK_F32, ASRK_BF16, ASRK_I16 = 0, 1, 2
 
 
 class AsrkError(RuntimeError):
@@ -68,6 +68,7 @@ _SIGNATURES = {
     "asrk_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "asrk_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "asrk_collate_pcm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asrk_find_token_i64": (c_int, [c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     "asrk_embed_splice": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),

@@ -185,9 +185,11 @@ def main():
     ap.add_argument("--workload", default="pipeline-small", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-input", action="store_true",
-                    help="diagnostic: each step starts from pinned host memory (adds the H2D copy of the padded waveforms; "
-                         "the contract's `value` is measured WITHOUT this flag, inputs resident in HBM)")
+    ap.add_argument("--host-input", nargs="?", const="sync", default=None, choices=["sync", "prefetch", "prefetch16"],
+                    help="diagnostic: each step starts from pinned host memory; the contract's `value` is measured WITHOUT "
+                         "this flag (inputs resident in HBM).  sync: H2D copy of the padded fp32 waveforms on the compute "
+                         "stream; prefetch / prefetch16: asr_amd.collate.FeaturePrefetcher (fp32 / int16 ragged buffer, copy "
+                         "on a side stream, pad + mask on the GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,7 +217,25 @@ def main():
     B = w["batch"]
     fe = LogMelFeatureExtractor(feature_size=w.get("n_mels", 80))
     wave = synth_audio(B, rank, device)
-    if args.host_input:
+    prefetch_iter = None
+    if args.host_input in ("prefetch", "prefetch16"):
+        from asr_amd.collate import FeaturePrefetcher, pack_ragged
+
+        w_np = wave.cpu().numpy()
+        if args.host_input == "prefetch16":
+            packed = pack_ragged([np.round(c * 32767).astype(np.int16) for c in w_np], np.int16)
+        else:
+            packed = pack_ragged(list(w_np), np.float32)
+
+        def _forever():
+            while True:
+                yield packed
+
+        prefetch_iter = iter(FeaturePrefetcher(fe, _forever(), depth=2))
+
+        def fetch():
+            raise RuntimeError("prefetch mode feeds features, not waveforms")
+    elif args.host_input:
         wave_host = wave.cpu().pin_memory()
         wave_dev = wave
 
@@ -225,6 +245,11 @@ def main():
     else:
         def fetch():
             return wave
+
+    def features():
+        if prefetch_iter is not None:
+            return next(prefetch_iter).input_features
+        return fe.extract_from_device(fetch())
     if args.workload == "splice":
         from asr_amd.splice import splice_audio_embeddings
 
@@ -240,7 +265,7 @@ def main():
             return splice_audio_embeddings(text, audio, ids, labels, chunk_id)[0]
     elif args.workload == "logmel":
         def step():
-            return fe.extract_from_device(fetch())
+            return features()
     elif w.get("train"):
         from asr_amd.distributed import FlatGradAllReducer
 
@@ -250,7 +275,7 @@ def main():
         g_up = (torch.randn((B, 1500, w["text_dim"]), device=device) * 1e-2).to(torch.bfloat16)
 
         def step():
-            feats = fe.extract_from_device(fetch())
+            feats = features()
             emb = proj(enc(feats))  # the encoder wrapper runs under no_grad (src/modeling.py:33-40)
             if reducer is not None:
                 reducer.zero_()  # .grad tensors are views of the reducer's flat buffer
@@ -266,7 +291,7 @@ def main():
 
         def step():
             with torch.no_grad():
-                feats = fe.extract_from_device(fetch())
+                feats = features()
                 return proj(enc(feats))
 
     def barrier():

@@ -40,7 +40,7 @@ enum {
     ASRK_ERR_LENGTH = -7       /* mel features are not 3000 frames long (HF modeling_whisper.py:612-616) */
 };
 
-enum { ASRK_F32 = 0, ASRK_BF16 = 1 };
+enum { ASRK_F32 = 0, ASRK_BF16 = 1, ASRK_I16 = 2 /* PCM input of asrk_collate_pcm only */ };
 
 int asrk_version(void);
 const char* asrk_strerror(int code);
@@ -164,6 +164,16 @@ int asrk_layernorm(const float* x, const float* w, const float* b, void* out, in
  * (the encoder's last norm, whose input is not needed again).  delta bf16 [M][D] is the out-proj / fc2 result. */
 int asrk_add_layernorm(float* x, const void* delta, const float* w, const float* b, void* out, int out_dtype,
                        int keep_x, int M, int D, float eps, void* stream);
+
+/* ---- on-device collate --------------------------------------------------------------
+ * The pad / truncate / mask step of the feature extractor (HF feature_extraction_whisper.py:300-307, 332-341;
+ * feature_extraction_sequence_utils.py:224-337) from one ragged device buffer: clip b = pcm[offsets[b] .. offsets[b+1])
+ * (ASRK_F32, or ASRK_I16 scaled by 1/32768), offsets int64 [B+1] on the device.
+ *   wave [B][target] f32: samples, right-padded with 0.0 / truncated to `target`;
+ *   frame_mask [B][target / hop] int32: 1 where frame * hop < min(len, target)   (= HF's attention_mask[:, ::hop]).
+ * Either output may be NULL. */
+int asrk_collate_pcm(const void* pcm, int pcm_dtype, const int64_t* offsets, int B, int target, int hop, float* wave,
+                     int* frame_mask, void* stream);
 
 /* ---- audio-embedding splice (src/modeling.py:222-276) ------------------------------
  * first_idx[b] = index of the first `token` in ids[b][0..L), -1 if absent (the reference's
