@@ -1,0 +1,90 @@
+"""Row f1 harness: WER by definition / known answers (jiwer is absent: parity unpinned), evaluate_samples' contract
+with stub model and tokenizer, and the generate() prompt splice on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from asr_amd.evaluation import evaluate_samples, word_error_rate
+
+
+def test_wer_known_answers():
+    assert word_error_rate(["hello world"], ["hello world"]) == 0.0
+    assert word_error_rate(["hello duck"], ["hello world"]) == 0.5                      # 1 substitution / 2
+    assert word_error_rate(["hello"], ["hello world"]) == 0.5                           # 1 deletion / 2
+    assert word_error_rate(["hello big world"], ["hello world"]) == 0.5                 # 1 insertion / 2
+    assert word_error_rate([""], ["a b c d"]) == 1.0
+    assert word_error_rate(["a b c d e f g h"], ["a"]) == 7.0                           # can exceed 1
+    # pooled over the corpus, not averaged per sentence: (1 + 0) / (2 + 6)
+    assert word_error_rate(["x b", "a b c d e f"], ["a b", "a b c d e f"]) == pytest.approx(1 / 8)
+    assert word_error_rate(["  the  cat\tsat "], ["the cat sat"]) == 0.0                # whitespace only separates
+    assert word_error_rate(["The cat"], ["the cat"]) == 0.5                             # no case folding
+    with pytest.raises(ValueError):
+        word_error_rate(["a"], ["a", "b"])
+    with pytest.raises(ValueError):
+        word_error_rate([""], [""])
+
+
+def test_wer_matches_bruteforce_alignment():
+    rng = np.random.default_rng(0)
+    vocab = ["a", "b", "c", "d"]
+
+    def brute(r, h):  # exhaustive recursion on tiny inputs
+        if not r:
+            return len(h)
+        if not h:
+            return len(r)
+        return min(brute(r[1:], h[1:]) + (r[0] != h[0]), brute(r[1:], h) + 1, brute(r, h[1:]) + 1)
+
+    for _ in range(40):
+        r = [vocab[i] for i in rng.integers(0, 4, size=rng.integers(1, 6))]
+        h = [vocab[i] for i in rng.integers(0, 4, size=rng.integers(0, 6))]
+        assert word_error_rate([" ".join(h)], [" ".join(r)]) == pytest.approx(brute(r, h) / len(r))
+
+
+def test_evaluate_samples_contract_with_stubs():
+    calls = []
+
+    class FE:
+        def __call__(self, audio, sampling_rate, return_tensors, return_attention_mask):
+            assert sampling_rate == 16000 and return_tensors == "pt" and return_attention_mask
+            f = torch.zeros((1, 80, 3000))
+
+            class R(dict):
+                __getattr__ = dict.__getitem__
+            return R(input_features=f, attention_mask=torch.ones((1, 3000), dtype=torch.int32))
+
+    class Model:
+        device = torch.device("cpu")
+
+        def generate(self, input_features, attention_mask, max_new_tokens, do_sample):
+            assert max_new_tokens == 100 and do_sample is False and attention_mask is not None
+            calls.append(tuple(input_features.shape))
+            return torch.tensor([[len(calls)]])
+
+    class Tok:
+        def decode(self, ids, skip_special_tokens):
+            assert skip_special_tokens
+            return {1: "the cat sat", 2: "a dog"}[int(ids[0])]
+
+    samples = [{"audio": {"array": np.zeros(16000, dtype=np.float32)}, "text": "the cat sat"},
+               {"audio": {"array": np.zeros(8000, dtype=np.float32)}, "sentence": "a big dog"}]
+    preds, refs, wer = evaluate_samples(Model(), Tok(), FE(), samples)
+    assert preds == ["the cat sat", "a dog"] and refs == ["the cat sat", "a big dog"]
+    assert wer == pytest.approx(1 / 6) and len(calls) == 2
+
+
+@pytest.mark.gpu
+def test_generate_prompt_splice_gpu():
+    from asr_amd.evaluation import build_generate_embeds
+
+    P, A, D, chunk = 12, 1500, 64, 49153
+    g = torch.Generator(device="cuda").manual_seed(0)
+    prompt = torch.randn((1, P, D), device="cuda", generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, 1000, (1, P), device="cuda", generator=g)
+    ids[0, 7] = chunk
+    audio = torch.randn((2, A, D), device="cuda", generator=g)  # fp32 projector output: cast like src/modeling.py:301
+    out = build_generate_embeds(prompt, ids, audio, chunk)
+    ref = torch.cat([prompt[0, :7], audio[0].to(torch.bfloat16), prompt[0, 8:]], dim=0)
+    assert tuple(out.shape) == (2, P - 1 + A, D) and torch.equal(out[0], ref) and torch.equal(out[1], ref)
+    with pytest.raises(ValueError, match="not found in instruction"):
+        build_generate_embeds(prompt, torch.zeros_like(ids), audio, chunk)
