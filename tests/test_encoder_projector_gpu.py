@@ -74,6 +74,31 @@ def test_encoder_stem_and_layers_match_oracle():
         assert err <= REL
 
 
+def test_encoder_big_batch_uses_256_tiles_and_matches_golden(golden_dir):
+    """With 96 clips every GEMM of the mid-size encoder (conv1 / conv2 as GEMMs over padded time-major rows, QKV,
+    out-proj, fc1, fc2) has >= 512 tiles of 256 x 256 and runs on the persistent / 256-tile kernels, which the
+    1-2 clip cases above never reach.  The batch is the fixture's two clips repeated; every copy must match the
+    HF golden output, wherever it sits in the batch."""
+    enc, sd, c = build_encoder("mid")
+    g = np.load(f"{golden_dir}/encoder_mid.npz")
+    x1 = torch.from_numpy(mg.encoder_features("mid"))[:1]
+    B = 96
+    x = x1.repeat(B, 1, 1).cuda()
+    x[1::2] = x[1::2].flip(2)  # every other clip time-reversed: a second, different input without a second fixture
+    y = enc(x).cpu().numpy()
+    assert y.shape == (B, 1500, c["d_model"]) and np.isfinite(y).all()
+    ref = g["out"][0]
+    for b in (0, 2, 46, 94):
+        err = rel_l2(y[b], ref)
+        assert err <= REL, f"clip {b}: rel-L2 {err:.3e}"
+    print(f"96-clip batch: rel-L2 {rel_l2(y[0], ref):.3e} / {rel_l2(y[94], ref):.3e}")
+    # clips are independent: equal inputs give bit-identical outputs within one launch, different inputs differ
+    assert np.array_equal(y[0], y[94]) and np.array_equal(y[1], y[95]) and not np.array_equal(y[0], y[1])
+    # and the reversed clips agree with the same clip run alone (128-tile kernels) to bf16 accuracy
+    y1 = enc(x[1:2]).cpu().numpy()
+    assert rel_l2(y[95], y1[0]) <= 5e-3
+
+
 def test_encoder_large_v3_dims_match_oracle():
     """Whisper-large-v3 widths (d 1280, 20 heads, ffn 5120, 128 mel bins; BASELINE.json configs[3]) on two layers:
     20 heads and K = 3 * 128 / 1280 / 5120 exercise tile counts the small-class cases do not.  Weights are too large

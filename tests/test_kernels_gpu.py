@@ -28,8 +28,10 @@ def _gelu(x):
     return 0.5 * x * (1.0 + torch.erf(x / np.sqrt(2.0)))
 
 
+# the last two shapes have >= 512 tiles of 256 x 256, so they dispatch to the persistent kernel (bf16 outputs) and to the
+# one-tile-per-workgroup 256 kernel (fp32 outputs); M is ragged in both, N = 960 also has a ragged last n-tile
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (1500, 768, 768), (300, 960, 768), (4500, 2304, 768),
-                                   (77, 132, 3072), (3000, 768, 256)])
+                                   (77, 132, 3072), (3000, 768, 256), (66017, 512, 128), (40003, 960, 192)])
 @pytest.mark.parametrize("mode", ["plain_bf16", "bias_gelu_bf16", "bias_res_f32", "alpha_f32"])
 def test_gemm(lib, M, N, K, mode):
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
@@ -73,6 +75,25 @@ def test_gemm_identity_asymmetric(lib):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(out, w.float().T)
+
+
+@pytest.mark.parametrize("out_bf16", [True, False])
+@pytest.mark.parametrize("M,N,K", [(66017, 512, 64), (33001, 1024, 128)])
+def test_gemm_large_tiles_exact(lib, M, N, K, out_bf16):
+    """The 256 x 256-tile kernels (persistent for bf16, one tile per workgroup for fp32) on small-integer operands:
+    every product sum is an integer <= 256 in magnitude, exact in fp32 and in bf16, so the result must be bit-exact
+    -- any wrong tile, row map, swizzle or ragged-edge handling shows as a mismatch, not as a tolerance."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randint(-1, 2, (M, K), device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (N, K), device="cuda", generator=g).to(torch.bfloat16)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    ref = x.float() @ w.float().T + bias
+    assert ref.abs().max().item() <= 256
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    rc = lib.asrk_gemm_bf16(_p(x), K, _p(w), _p(bias), _p(None), 0, 0, _p(out), N, int(out_bf16), M, N, K, 0, 1.0, _stream())
+    assert rc == 0, lib.asrk_strerror(rc)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float(), ref)
 
 
 def test_gemm_rejects_bad_shapes(lib):
