@@ -190,6 +190,33 @@ def test_projector_input_grad_and_inference_path_match_oracle():
     assert rel_l2(y_bf.float().cpu().numpy(), y_ref.numpy()) <= REL
 
 
+def test_projector_big_batch_forward_backward_vs_torch_fp32():
+    """M = 44 x 1500 rows: linear_1 / linear_2 (N = 960, ragged last n-tile) and the dH GEMM with the fused gelu'
+    factor run on the 256-tile kernels, which the golden cases (M <= 3000) never reach.  Checker: the same module
+    arithmetic (LlamaRMSNorm -> linear -> exact GELU -> linear -> x 0.01, src/modeling.py:77-84) in plain fp32 torch
+    with autograd, on the same GPU -- the CPU oracle would take minutes at this size."""
+    proj, sd, c = build_projector("p768")
+    B, T, D = 44, 1500, c["audio_dim"]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B, T, D), device="cuda", generator=g)
+    gy = torch.randn((B, T, c["text_dim"]), device="cuda", generator=g) * 1e-2
+    y = proj(x)
+    y.backward(gy)
+    mine = {n: p.grad.clone() for n, p in proj.named_parameters()}
+    ref_p = {n: p.detach().clone().requires_grad_(True) for n, p in proj.named_parameters()}
+    xn = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * ref_p["norm.weight"]
+    h = torch.nn.functional.gelu(xn @ ref_p["linear_1.weight"].T + ref_p["linear_1.bias"])
+    y_ref = (h @ ref_p["linear_2.weight"].T + ref_p["linear_2.bias"]) * 0.01
+    y_ref.backward(gy)
+    fe = rel_l2(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy())
+    print(f"big projector batch: forward rel-L2 {fe:.3e}")
+    assert fe <= REL
+    for n in mine:
+        e = rel_l2(mine[n].cpu().numpy(), ref_p[n].grad.cpu().numpy())
+        print(f"   grad {n}: rel-L2 {e:.3e}")
+        assert e <= 2e-2, f"grad {n}: {e:.3e}"
+
+
 def test_projector_init_matches_reference_statistics():
     from asr_amd.projector import AudioProjector
 
