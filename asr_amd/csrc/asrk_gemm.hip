@@ -162,14 +162,16 @@ int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st
         return ASRK_ERR_ALIGN;
     if ((a.x_bs % 8) || (a.x_rs % 8) || (a.o_bs % 4) || (a.o_rs % 4) || (a.o_off % 4) || (a.ldr % 4))
         return ASRK_ERR_ALIGN;
-    // Tile choice: 256 x 256 tiles (one workgroup per CU, deep prefetch) once there are enough of
-    // them to fill the chip several times over; 128 x 128 tiles otherwise.  ASRK_GEMM_TILE=128|256
-    // overrides (A/B measurements only).
+    // Tile choice: 256 x 256 tiles (one workgroup per CU) once there are enough of them, 128 x 128 tiles otherwise.
+    // Measured crossovers (tools/gemm_bench.py, M swept from 1500 to 96000): the persistent bf16-output kernel wins
+    // from about half a tile per CU (141 tiles: 22 us against 28 us; 72 tiles lose), the one-tile-per-workgroup
+    // fp32-output kernel only with several rounds of tiles.  ASRK_GEMM_TILE=128|256 overrides (A/B measurements only).
     static const int forced = [] { const char* e = getenv("ASRK_GEMM_TILE"); return e ? atoi(e) : 0; }();
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long min_tiles = out_bf16 ? 136 : 512;
     // a ragged last n-tile is fine while at least 7/8 of the tiles' columns are real (N = 960: 93.75 %)
     const long n_cover = (long)((a.N + 255) / 256) * 256;
-    const bool big = a.splits == 1 && (forced == 256 || (forced == 0 && tiles256 >= 512 && 8L * a.N >= 7L * n_cover)) &&
+    const bool big = a.splits == 1 && (forced == 256 || (forced == 0 && tiles256 >= min_tiles && 8L * a.N >= 7L * n_cover)) &&
                      (a.N % 8) == 0;
     if (big) return asrk_gemm256_launch(a, gelu, out_bf16, st);
     if (gelu) return out_bf16 ? launch<true, true>(a, st) : launch<true, false>(a, st);

@@ -25,6 +25,10 @@ SHAPES = {
     "fc2_bf16": (768, 3072, 0, 1, 1, 0),
     "proj1": (960, 768, 1, 1, 1, 0),        # projector linear_1 + GELU, linear_2 (N = 960: ragged last n-tile)
     "proj2": (960, 960, 0, 1, 1, 0),
+    "l_qkv": (3840, 1280, 0, 1, 1, 0),      # large-v3 widths (use --M 24000 for 16 clips)
+    "l_out": (1280, 1280, 0, 1, 1, 0),
+    "l_fc1": (5120, 1280, 1, 1, 1, 0),
+    "l_fc2": (1280, 5120, 0, 1, 1, 0),
     "sq4k": (4096, 4096, 0, 1, 0, 0),
 }
 
