@@ -76,6 +76,7 @@ _SIGNATURES = {
     "asrk_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p]),
     "asrk_attention_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "asrk_attention_log2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "asrk_profile_enable": (c_int, [c_int]),
     "asrk_profile_read": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_int]),
 }

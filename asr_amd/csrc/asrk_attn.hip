@@ -285,3 +285,9 @@ int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, b
 extern "C" int asrk_attention_bf16(const void* qkv, void* out, int B, int T, int H, void* stream) {
     return asrk_launch_attention((const bf16_t*)qkv, (bf16_t*)out, B, T, H, false, (hipStream_t)stream);
 }
+
+// Same, for q that already carries the factor log2(e) on top of head_dim^-0.5 (what the encoder feeds: it folds both
+// into W_q / b_q); exported so that the log2-domain path, including its reference handling, has a parity test.
+extern "C" int asrk_attention_log2_bf16(const void* qkv, void* out, int B, int T, int H, void* stream) {
+    return asrk_launch_attention((const bf16_t*)qkv, (bf16_t*)out, B, T, H, true, (hipStream_t)stream);
+}

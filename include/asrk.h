@@ -195,6 +195,9 @@ int asrk_embed_splice_backward(const void* grad_out, const int* chunk_idx, int B
  * (modeling_whisper.py:215-238, 341-351).  qkv bf16 [B*T][3*H*64] (q | k | v per row),
  * out bf16 [B*T][H*64]. */
 int asrk_attention_bf16(const void* qkv, void* out, int B, int T, int H, void* stream);
+/* The same with q pre-multiplied by log2(e) as well (scores in log2 units): the form asrk_encoder_forward uses, the
+ * factor being folded into W_q and b_q when the weights are packed. */
+int asrk_attention_log2_bf16(const void* qkv, void* out, int B, int T, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference, which has no profiler: SURVEY section 5).

@@ -161,6 +161,34 @@ def test_attention(lib, B, T, H):
     assert err <= 2e-2, f"max err {err:.3e}"
 
 
+@pytest.mark.parametrize("scale,shift", [(0.35, 0.0), (6.0, 0.0), (3.0, 9.0), (0.35, -9.0)])
+def test_attention_log2_domain(lib, scale, shift):
+    """The encoder's form: q pre-multiplied by log2(e).  Small scores, large ones (|s| up to a few hundred in log2
+    units), a large common offset and late jumps of the running maximum exercise the lazy reference moves."""
+    B, T, H = 2, 1500, 3
+    d = 64 * H
+    g = torch.Generator(device="cuda").manual_seed(int(scale * 100) + int(shift))
+    q = torch.randn((B * T, d), device="cuda", generator=g) * scale
+    k = torch.randn((B * T, d), device="cuda", generator=g) + shift * torch.sign(q.mean(0, keepdim=True) + 1e-3)
+    v = torch.randn((B * T, d), device="cuda", generator=g)
+    k[B * T // 2 + 100:B * T // 2 + 110] *= 4.0  # a late jump of the running maximum for many queries
+    qkv_nat = torch.cat([q, k, v], dim=1).to(torch.bfloat16)                    # natural-log scores (reference)
+    qkv_l2 = torch.cat([q * 1.4426950408889634, k, v], dim=1).to(torch.bfloat16)
+    qkv_l2[:, d:] = qkv_nat[:, d:]
+    out = torch.full((B * T, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    assert lib.asrk_attention_log2_bf16(_p(qkv_l2), _p(out), B, T, H, _stream()) == 0
+    torch.cuda.synchronize()
+    # reference on the SAME rounded q: undo the log2(e) factor in fp32
+    qf = (qkv_l2[:, :d].float() / 1.4426950408889634).view(B, T, H, 64).transpose(1, 2)
+    kf = qkv_l2[:, d:2 * d].float().view(B, T, H, 64).transpose(1, 2)
+    vf = qkv_l2[:, 2 * d:].float().view(B, T, H, 64).transpose(1, 2)
+    ref = torch.softmax(qf @ kf.transpose(-1, -2), dim=-1) @ vf
+    ref = ref.transpose(1, 2).reshape(B * T, d)
+    assert torch.isfinite(out.float()).all()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
 def test_attention_online_softmax_rescale(lib):
     """Force the running-max rescale: one key, late in the sequence, dominates one query."""
     B, T, H = 1, 320, 1
