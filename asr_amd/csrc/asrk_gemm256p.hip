@@ -21,6 +21,8 @@
 #include "asrk_prof.h"
 
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #ifdef ASRK_STAMPS
 __device__ unsigned long long g_pstamps[1024 * 8];
@@ -48,7 +50,17 @@ constexpr int PATCH = 4096;          // private epilogue patch per wave
 constexpr int LDS_BYTES = RING + 8 * PATCH;
 static_assert(LDS_BYTES == 163840, "uses all of the CU's LDS");
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 __device__ __forceinline__ void wait_all_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+// waits for everything but this wave's N youngest vector-memory operations
+template <int N>
+__device__ __forceinline__ void wait_older() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Orders this wave's LDS stores before its following LDS loads of other lanes' data (the hardware runs a
 // wave's LDS operations in order; this only stops the compiler from moving them).
@@ -58,22 +70,101 @@ __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wave's 128 x 64 block (rows mw.., columns nw..) from accumulators to memory.
-template <int MT, bool GELU, bool OUT_BF16>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4][MT], float bias_lane, char* patch,
-                                              int mw, int nw, int lane) {
+// LDS accesses of the fast epilogue, as asm: the compiler puts s_waitcnt vmcnt(0) in front of any LDS access of its own
+// that follows a global_load_lds it cannot tell apart (here: slice 1 of the next tile, issued just before the
+// epilogue and wanted two slices later), which would expose a full memory round trip per tile.  LDS operations of a wave
+// complete in order; the waits are explicit.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(p); }
+template <int OFF>
+__device__ __forceinline__ void lds_write8(uint32_t addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// waits until at most N LDS operations of this wave are outstanding; the operands tie the loaded values to the wait
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2 };  // DGELU: times gelu'(dg_pre[m][n]) (projector backward)
+
+// One wave's 128 x 64 block (rows mw.., columns nw..) from accumulators to memory.  The caller has put this block's 64
+// bias values at the start of the patch (one float per lane).
+template <int MT, int EPI, bool OUT_BF16>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4][MT], char* patch, int mw, int nw, int lane) {
+    constexpr bool GELU = EPI == EPI_GELU;
     const int frow = lane & 15, fq = lane >> 4;
-    // bias_lane = bias[nw + lane]; a lane needs columns nw + 16 nt + 4 fq .. +3
+    // a lane needs the bias of columns nw + 16 nt + 4 fq .. +3
     f32x4 bv[4];
-    reinterpret_cast<float*>(patch)[lane] = bias_lane;
     wave_lds_order();
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(patch + (nt * 16 + fq * 4) * 4);
     wave_lds_order();
     const float alpha = a.alpha;  // locals, not a.*: see gemm_epilogue_value
-    const bf16_t* const dg_pre = a.dg_pre;
+    const bf16_t* const dg_pre = EPI == EPI_DGELU ? a.dg_pre : nullptr;
     const int64_t ld_dg = a.ld_dg;
     const int M = a.M, N = a.N;
+    if (OUT_BF16 && EPI != EPI_DGELU) {
+        // Fast path (every tile of the encoder's GEMMs but the ragged edge): the block lies inside the matrix and
+        // inside one block of the output row map, so row r of it is at base + r * o_rs with a wave-uniform base.
+        // Straight-line code: no per-row division, no 64-bit lane arithmetic, no predication -- the general path
+        // below spends 8.5 k cycles per tile on exactly those, stores or no stores.
+        const int q0 = mw / a.o_rpb, r0 = mw - q0 * a.o_rpb;
+        if (mw + 16 * MT <= M && nw + 64 <= N && r0 + 16 * MT <= a.o_rpb && a.o_rs < (1 << 24)) {
+            const int r8 = lane >> 3, c8 = lane & 7;
+            const int o_rs = (int)a.o_rs;
+            bf16_t* const base = reinterpret_cast<bf16_t*>(a.out) + a.o_off + (int64_t)q0 * a.o_bs + (int64_t)r0 * a.o_rs + nw;
+            const int lane_off = r8 * o_rs + c8 * 8;
+            // two [16][64] bf16 half-patches used alternately (layout: see the general path below)
+            uint32_t wa[4], ra[2];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wa[nt] = lds_addr(patch) + frow * 128 + (((nt * 4 + fq) ^ frow) << 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ra[h] = lds_addr(patch) + (h * 8 + r8) * 128 + ((c8 ^ ((h * 8 + r8) >> 1)) << 4);
+            auto put = [&](auto mt_c) {  // 16 rows of accumulators -> half-patch mt & 1
+                constexpr int mt = decltype(mt_c)::value;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 v = acc[nt][mt] + bv[nt];
+                    if (GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                    }
+                    v *= alpha;
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                    lds_write8<(mt & 1) * 2048>(wa[nt], __builtin_bit_cast(u32x2, o));
+                }
+            };
+            put(std::integral_constant<int, 0>{});
+            static_for<MT>([&](auto mt_c) {
+                constexpr int mt = decltype(mt_c)::value;
+                u32x4 v0 = lds_read16<(mt & 1) * 2048>(ra[0]);
+                u32x4 v1 = lds_read16<(mt & 1) * 2048>(ra[1]);
+                if constexpr (mt + 1 < MT) {
+                    put(std::integral_constant<int, mt + 1>{});
+                    lds_wait<4>(v0, v1);  // in order: only the 4 writes of the next group may still be outstanding
+                } else {
+                    lds_wait<0>(v0, v1);
+                }
+                if (r8 & 1) {  // rows h * 8 + r8: odd rows hold their 8-byte halves swapped
+                    v0 = u32x4{v0.z, v0.w, v0.x, v0.y};
+                    v1 = u32x4{v1.z, v1.w, v1.x, v1.y};
+                }
+                *reinterpret_cast<u32x4*>(base + (int64_t)((mt * 16) * o_rs) + lane_off) = v0;
+                *reinterpret_cast<u32x4*>(base + (int64_t)((mt * 16 + 8) * o_rs) + lane_off) = v1;
+            });
+            return;
+        }
+    }
     if (OUT_BF16) {
         // Two [16][64] bf16 half-patches (2 KiB each), used alternately so the stores of one 16-row group overlap
         // the staging of the next.  8-byte unit u of row r lives at unit u ^ r: conflict-free for the
@@ -158,7 +249,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
     }
 }
 
-template <int MT, bool GELU, bool OUT_BF16>
+template <int MT, int EPI, bool OUT_BF16>
 __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     constexpr int BM = 32 * MT;          // 2 waves along m, 16 * MT rows each
     constexpr int XOPER = BM * RB;       // bytes of the X slice
@@ -247,51 +338,61 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     int t = lidx;
     int m0 = (tm_lo + t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
     set_sources(m0, n0);
-    // start-up phase skew (ASRK_GEMM_SKEW, measurements): spread the workgroups' tile phases so that the epilogue
-    // stores of some CUs run under the K loops of the others instead of all at once
-    if (a.skew > 0) {
-        const int n = ((blockIdx.x >> 3) & 7) * a.skew;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     PSTAMP(0);
     stage(0, 0);
+    stage(1, 1);
+    wait_older<GX + GW>();  // slice 0
     int slot = 0;
 #ifdef ASRK_STAMPS
     int tile_no = 0;
 #endif
+    // A tile enters its K loop with slices 0 and 1 staged (slice 1 possibly still in flight).  Slice kt + 1 is
+    // staged at the top of iteration kt >= 1; the last iteration stages slice 0 of the next tile, and slice 1 of
+    // the next tile follows right after the loop, BEFORE the epilogue: a wave's vector-memory operations complete in
+    // issue order, so loads issued behind the epilogue's 16 stores wait until those have drained (measured:
+    // 7.6 k cycles per tile lost in the K loop that followed the epilogue when slice 1 was staged after it).
     while (true) {
         const int tnext = t + wgs_per_xcd;
         const bool has_next = tnext < count;
         int m0n = 0, n0n = 0;
+#pragma nounroll  // also keeps the kt == 0 case from being peeled into a second copy of the body (spills)
         for (int kt = 0; kt < nkt; ++kt) {
-            // my loads of this slice have landed (and my stores of the previous tile have drained); after the
-            // barrier everyone's have, and everyone has finished reading the other slot
-            wait_all_barrier();
+            // my loads of this slice have landed (slice 0: waited for before the previous epilogue / the loop);
+            // after the barrier everyone's have, and everyone has finished reading the other slot
+            if (kt == 0) asm volatile("s_barrier" ::: "memory"); else wait_all_barrier();
 #ifdef ASRK_STAMPS
             if (kt == 0) { if (tile_no == 0) PSTAMP(1); else if (tile_no == 1) PSTAMP(5); }
 #endif
-            if (kt + 1 < nkt) {
-                stage(kt + 1, slot ^ 1);
-            } else {
+            if (kt >= 1 && kt + 1 < nkt) stage(kt + 1, slot ^ 1);
+            if (kt + 1 == nkt) {
                 // this tile's bias, one column per lane (spread to the accumulator layout through the LDS patch in
-                // the epilogue).  Issued BEFORE the next tile's first global_load_lds: loads return in order, so
-                // the epilogue waits for it with those 8 still in flight instead of draining them.
+                // the epilogue), issued before the next tile's loads so that it is older than all of them
                 const int n = n0 + wn * 64 + lane;
                 bias_lane = (a.bias && n < a.N) ? a.bias[n] : 0.f;
-            }
-            if (kt + 1 == nkt && has_next) {  // the K stream runs on into the next tile
-                m0n = (tm_lo + tnext / tiles_n) * BM;
-                n0n = (tnext % tiles_n) * BN;
-                set_sources(m0n, n0n);
-                stage(0, slot ^ 1);
+                if (has_next) {  // the K stream runs on into the next tile
+                    m0n = (tm_lo + tnext / tiles_n) * BM;
+                    n0n = (tnext % tiles_n) * BN;
+                    set_sources(m0n, n0n);
+                    stage(0, slot ^ 1);
+                }
             }
             compute(smem + slot * STAGE);
             slot ^= 1;
         }
+        // The bias goes to the patch first: the wait for its load (older than every load of the next tile) sits here,
+        // where those have had a whole slice of MFMAs to land, and the epilogue proper then never waits on vmcnt.
+        char* const patch = smem + RING + wave * PATCH;
+        reinterpret_cast<float*>(patch)[lane] = bias_lane;
+        if (has_next) {
+            // slice 0 of the next tile has landed; once everyone has finished reading the slot of the last slice,
+            // slice 1 of the next tile goes there
+            wait_all_barrier();
+            stage(1, slot ^ 1);
+        }
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(2);
 #endif
-        epilogue_wave<MT, GELU, OUT_BF16>(a, acc, bias_lane, smem + RING + wave * PATCH, m0 + wm * (16 * MT), n0 + wn * 64, lane);
+        epilogue_wave<MT, EPI, OUT_BF16>(a, acc, patch, m0 + wm * (16 * MT), n0 + wn * 64, lane);
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(3); else if (tile_no == 1) PSTAMP(6);
         ++tile_no;
@@ -330,17 +431,14 @@ double schedule_cost(const GemmArgs& a, int mt) {
     return (double)rounds * (mt == 8 ? 1.0 : 0.84);
 }
 
-template <int MT, bool GELU, bool OUT_BF16>
-int launch(const GemmArgs& a_in, hipStream_t st) {
-    GemmArgs a = a_in;
-    static const int skew = [] { const char* e = getenv("ASRK_GEMM_SKEW"); return e ? atoi(e) : 0; }();
-    a.skew = skew;
+template <int MT, int EPI, bool OUT_BF16>
+int launch(const GemmArgs& a, hipStream_t st) {
     constexpr int BM = 32 * MT;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per_xcd = ((tiles_m + 7) / 8) * tiles_n;  // tiles of the fullest XCD
     int wgs_per_xcd = device_cus() / 8;
     if (per_xcd < wgs_per_xcd) wgs_per_xcd = per_xcd;
-    auto kern = gemm256p_kernel<MT, GELU, OUT_BF16>;
+    auto kern = gemm256p_kernel<MT, EPI, OUT_BF16>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
         return ASRK_ERR_HIP;
     AsrkProfScope prof(ASRK_PROF_GEMM, 2.0 * a.M * a.N * a.K, st);
@@ -350,15 +448,19 @@ int launch(const GemmArgs& a_in, hipStream_t st) {
 
 template <int MT>
 int dispatch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
-    if (gelu) return out_bf16 ? launch<MT, true, true>(a, st) : launch<MT, true, false>(a, st);
-    return out_bf16 ? launch<MT, false, true>(a, st) : launch<MT, false, false>(a, st);
+    if (a.dg_pre) {
+        if (gelu) return ASRK_ERR_SHAPE;  // gelu and gelu' never combine (asrk_gemm.hip's contract)
+        return out_bf16 ? launch<MT, EPI_DGELU, true>(a, st) : launch<MT, EPI_DGELU, false>(a, st);
+    }
+    if (gelu) return out_bf16 ? launch<MT, EPI_GELU, true>(a, st) : launch<MT, EPI_GELU, false>(a, st);
+    return out_bf16 ? launch<MT, EPI_NONE, true>(a, st) : launch<MT, EPI_NONE, false>(a, st);
 }
 
 }  // namespace
 
 // Arguments are validated by asrk_gemm_launch (asrk_gemm.hip); needs splits == 1, N % 8 == 0, K % 64 == 0.
 int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
-    if (a.splits != 1 || (a.N % 8) != 0 || (a.K % BK) != 0) return ASRK_ERR_SHAPE;
+    if (a.splits != 1 || (a.N % 8) != 0 || (a.K % BK) != 0 || a.K < 2 * BK) return ASRK_ERR_SHAPE;
     // ASRK_GEMM_MT (A/B measurements only): 8 or 6 forces the tile height
     static const int forced = [] { const char* e = getenv("ASRK_GEMM_MT"); return e ? atoi(e) : 0; }();
     const bool use6 = forced == 6 || (forced != 8 && schedule_cost(a, 6) < schedule_cost(a, 8));

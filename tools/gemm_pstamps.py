@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "asr_amd", "libasrk_diag.so"))
+lib = ctypes.CDLL(os.environ.get("ASRK_DIAG_LIB", os.path.join(ROOT, "asr_amd", "libasrk_diag.so")))
 from ctypes import c_float, c_int, c_int64, c_void_p  # noqa: E402
 
 lib.asrk_gemm_bf16.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,
