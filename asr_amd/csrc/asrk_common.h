@@ -36,6 +36,34 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(fabsf(h), fmaf(-p, e, 1.0f), h);
 }
 
+// The same for two values at once on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per
+// issue; an epilogue is pure VALU, there is no MFMA beside it to disturb).  Returns 2 * gelu(x) so that the caller can
+// fold the 0.5 into its own scale.  11 packed + 2 plain + 4 transcendental issues per pair: 42 cycles per value against
+// 68 for gelu_erf.  Coefficients negated so that erf = 1 + q e needs no sign flip.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf_x2(f32x2_t x) {
+    f32x2_t ax;
+    ax.x = __builtin_fabsf(x.x);
+    ax.y = __builtin_fabsf(x.y);
+    const f32x2_t one = {1.0f, 1.0f};
+    const f32x2_t d = __builtin_elementwise_fma(ax, f32x2_t{0.23164189f, 0.23164189f}, one);  // 1 + 0.3275911 |x| / sqrt 2
+    f32x2_t t;
+    t.x = __builtin_amdgcn_rcpf(d.x);
+    t.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2_t q = __builtin_elementwise_fma(t, f32x2_t{-1.061405429f, -1.061405429f}, f32x2_t{1.453152027f, 1.453152027f});
+    q = __builtin_elementwise_fma(t, q, f32x2_t{-1.421413741f, -1.421413741f});
+    q = __builtin_elementwise_fma(t, q, f32x2_t{0.284496736f, 0.284496736f});
+    q = __builtin_elementwise_fma(t, q, f32x2_t{-0.254829592f, -0.254829592f});
+    q = q * t;
+    const f32x2_t s = x * f32x2_t{0.84932180028801904f, 0.84932180028801904f};  // sqrt(log2(e) / 2)
+    const f32x2_t ss = s * -s;
+    f32x2_t e;
+    e.x = __builtin_amdgcn_exp2f(ss.x);  // exp(-x^2 / 2)
+    e.y = __builtin_amdgcn_exp2f(ss.y);
+    const f32x2_t w = __builtin_elementwise_fma(q, e, one);  // erf(|x| / sqrt 2)
+    return __builtin_elementwise_fma(ax, w, x);              // x + |x| erf(|x| / sqrt 2) = 2 gelu(x)
+}
+
 // d/dx of the exact GELU: Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

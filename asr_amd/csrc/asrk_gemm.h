@@ -40,10 +40,11 @@ __device__ __forceinline__ f32x4 gemm_epilogue_value(float alpha, const bf16_t* 
                                                      f32x4 bv, int m, int n) {
     v += bv;
     if (GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        const f32x2_t lo = gelu_erf_x2(f32x2_t{v[0], v[1]}), hi = gelu_erf_x2(f32x2_t{v[2], v[3]});
+        v = f32x4{lo.x, lo.y, hi.x, hi.y} * (0.5f * alpha);
+    } else {
+        v *= alpha;
     }
-    v *= alpha;
     if (dg_pre && in_range) {
         const bf16x4 pz = *reinterpret_cast<const bf16x4*>(dg_pre + (int64_t)m * ld_dg + n);
 #pragma unroll
@@ -66,10 +67,11 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& a, f32x4 v, 
                                                     const float* rrow) {
     v += bv;
     if (GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        const f32x2_t lo = gelu_erf_x2(f32x2_t{v[0], v[1]}), hi = gelu_erf_x2(f32x2_t{v[2], v[3]});
+        v = f32x4{lo.x, lo.y, hi.x, hi.y} * (0.5f * a.alpha);
+    } else {
+        v *= a.alpha;
     }
-    v *= a.alpha;
     if (a.dg_pre && m < a.M && n < a.N) {
         const bf16x4 pz = *reinterpret_cast<const bf16x4*>(a.dg_pre + (int64_t)m * a.ld_dg + n);
 #pragma unroll

@@ -134,10 +134,11 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
                 for (int nt = 0; nt < 4; ++nt) {
                     f32x4 v = acc[nt][mt] + bv[nt];
                     if (GELU) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                        const f32x2_t lo = gelu_erf_x2(f32x2_t{v[0], v[1]}), hi = gelu_erf_x2(f32x2_t{v[2], v[3]});
+                        v = f32x4{lo.x, lo.y, hi.x, hi.y} * (0.5f * alpha);
+                    } else {
+                        v *= alpha;
                     }
-                    v *= alpha;
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];

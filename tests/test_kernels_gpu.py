@@ -96,6 +96,34 @@ def test_gemm_large_tiles_exact(lib, M, N, K, out_bf16):
     assert torch.equal(out.float(), ref)
 
 
+@pytest.mark.parametrize("M,out_bf16", [(4096, False), (70000, True)])
+def test_gemm_gelu_epilogue_accuracy(lib, M, out_bf16):
+    """W = I, so out = alpha * gelu(x + bias) element by element: the packed-fp32 erf GELU of the epilogues against
+    float64 erf.  fp32 output (128-tile and one-tile 256 kernels): |err| <= 1e-6 * max(1, |x|); bf16 output at a size
+    that takes the persistent kernel's straight-line epilogue: exact to bf16 rounding."""
+    K = N = 256
+    g = torch.Generator(device="cuda").manual_seed(M)
+    x = (torch.rand((M, K), device="cuda", generator=g) * 24.0 - 12.0).to(torch.bfloat16)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-3, -1e-3, 12.0, -12.0, 40.0, -40.0], device="cuda").to(torch.bfloat16)
+    w = torch.eye(N, K, device="cuda").to(torch.bfloat16)
+    bias = torch.rand((N,), device="cuda", generator=g) - 0.5
+    alpha = 1.25
+    pre = x.double() + bias.double()
+    ref = alpha * 0.5 * pre * (1.0 + torch.erf(pre / np.sqrt(2.0)))
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    rc = lib.asrk_gemm_bf16(_p(x), K, _p(w), _p(bias), _p(None), 0, 0, _p(out), N, int(out_bf16), M, N, K, 1, alpha, _stream())
+    assert rc == 0, lib.asrk_strerror(rc)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    if out_bf16:
+        # fp32 value within 2e-6 of the truth, then one bf16 rounding (relative 2^-9 incl. ties)
+        err = (out.double() - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -8 + 4e-6).all(), err.max().item()
+    else:
+        err = (out.double() - ref).abs() / pre.abs().clamp(min=1.0)
+        assert err.max().item() <= 1.5e-6, err.max().item()
+
+
 def test_gemm_rejects_bad_shapes(lib):
     x = torch.zeros((64, 96), device="cuda", dtype=torch.bfloat16)
     out = torch.zeros((64, 64), device="cuda")
