@@ -28,11 +28,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* x, const bf16_t* 
     for (int i = 0; i < MAX_V4; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-            v[i] = xr[c];
             if (ADD) {
-                const bf16x4 dv = reinterpret_cast<const bf16x4*>(delta + (size_t)row * D)[c];
-                v[i].x += (float)dv[0]; v[i].y += (float)dv[1]; v[i].z += (float)dv[2]; v[i].w += (float)dv[3];
-                if (KEEP_X) reinterpret_cast<float4*>(x + (size_t)row * D)[c] = v[i];
+                // the fp32 residual stream and the delta are touched once per layer step: non-temporal, so that what
+                // stays in the memory-side cache is the bf16 output the next GEMM reads
+                const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr) + c);
+                const bf16x4 dv = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(delta + (size_t)row * D) + c);
+                f32x4 sum = xv + f32x4{(float)dv[0], (float)dv[1], (float)dv[2], (float)dv[3]};
+                v[i] = float4{sum[0], sum[1], sum[2], sum[3]};
+                if (KEEP_X) __builtin_nontemporal_store(sum, reinterpret_cast<f32x4*>(x + (size_t)row * D) + c);
+            } else {
+                v[i] = xr[c];
             }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
