@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/asrk.h"
 
@@ -86,6 +88,19 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// LDS byte address of a pointer into __shared__ memory (operand of hand-written ds_* instructions)
+__device__ __forceinline__ uint32_t lds_addr32(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(p); }
 
 #define ASRK_CHECK_HIP(expr)                                  \
     do {                                                      \

@@ -21,8 +21,6 @@
 #include "asrk_prof.h"
 
 #include <cstdlib>
-#include <type_traits>
-#include <utility>
 
 #ifdef ASRK_STAMPS
 __device__ unsigned long long g_pstamps[1024 * 8];
@@ -50,13 +48,6 @@ constexpr int PATCH = 4096;          // private epilogue patch per wave
 constexpr int LDS_BYTES = RING + 8 * PATCH;
 static_assert(LDS_BYTES == 163840, "uses all of the CU's LDS");
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
 __device__ __forceinline__ void wait_all_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
 // waits for everything but this wave's N youngest vector-memory operations
 template <int N>
@@ -74,9 +65,7 @@ __device__ __forceinline__ void wave_lds_order() {
 // that follows a global_load_lds it cannot tell apart (here: slice 1 of the next tile, issued just before the
 // epilogue and wanted two slices later), which would expose a full memory round trip per tile.  LDS operations of a wave
 // complete in order; the waits are explicit.
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(p); }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return lds_addr32(p); }
 template <int OFF>
 __device__ __forceinline__ void lds_write8(uint32_t addr, u32x2 v) {
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
