@@ -334,7 +334,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     PSTAMP(0);
     stage(0, 0);
     stage(1, 1);
-    wait_older<GX + GW>();  // slice 0
+    wait_older<GX + GW>();  // my part of slice 0 ...
+    asm volatile("s_barrier" ::: "memory");  // ... and everyone's
     int slot = 0;
 #ifdef ASRK_STAMPS
     int tile_no = 0;
@@ -350,9 +351,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         int m0n = 0, n0n = 0;
 #pragma nounroll  // also keeps the kt == 0 case from being peeled into a second copy of the body (spills)
         for (int kt = 0; kt < nkt; ++kt) {
-            // my loads of this slice have landed (slice 0: waited for before the previous epilogue / the loop);
-            // after the barrier everyone's have, and everyone has finished reading the other slot
-            if (kt == 0) asm volatile("s_barrier" ::: "memory"); else wait_all_barrier();
+            // my loads of this slice have landed; after the barrier everyone's have, and everyone has finished
+            // reading the other slot.  Slice 0 needs neither: it was complete for every wave at the barrier in front
+            // of the previous epilogue (or of the loop), and nothing is staged at kt == 0 -- so a wave that leaves
+            // its epilogue early starts on slice 0 while its SIMD partner is still storing.
+            if (kt > 0) wait_all_barrier();
 #ifdef ASRK_STAMPS
             if (kt == 0) { if (tile_no == 0) PSTAMP(1); else if (tile_no == 1) PSTAMP(5); }
 #endif
