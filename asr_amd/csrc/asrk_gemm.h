@@ -31,6 +31,7 @@ struct GemmArgs {
 int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);
 int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);  // 256x256 tiles, splits == 1
 int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st);  // same, persistent workgroups
+bool asrk_gemm256p_fits(const GemmArgs& a);  // operands within the persistent kernel's 32-bit offsets
 
 // Element part of the epilogue (everything except residual and store) for 4 consecutive n of row m.
 // `bv` is the bias of those 4 columns, loaded once by the caller (it does not depend on the row: a load

@@ -48,6 +48,12 @@ constexpr int PATCH = 4096;          // private epilogue patch per wave
 constexpr int LDS_BYTES = RING + 8 * PATCH;
 static_assert(LDS_BYTES == 163840, "uses all of the CU's LDS");
 
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void wait_all_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
 // waits for everything but this wave's N youngest vector-memory operations
 template <int N>
@@ -92,9 +98,16 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
     const int frow = lane & 15, fq = lane >> 4;
     // a lane needs the bias of columns nw + 16 nt + 4 fq .. +3
     f32x4 bv[4];
-    wave_lds_order();
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(patch + (nt * 16 + fq * 4) * 4);
+    {
+        const uint32_t ba = lds_addr(patch) + fq * 16;
+        u32x4 b0 = lds_read16<0>(ba), b1 = lds_read16<64>(ba), b2 = lds_read16<128>(ba), b3 = lds_read16<192>(ba);
+        lds_wait<0>(b0, b1);
+        lds_wait<0>(b2, b3);
+        bv[0] = __builtin_bit_cast(f32x4, b0);
+        bv[1] = __builtin_bit_cast(f32x4, b1);
+        bv[2] = __builtin_bit_cast(f32x4, b2);
+        bv[3] = __builtin_bit_cast(f32x4, b3);
+    }
     wave_lds_order();
     const float alpha = a.alpha;  // locals, not a.*: see gemm_epilogue_value
     const bf16_t* const dg_pre = EPI == EPI_DGELU ? a.dg_pre : nullptr;
@@ -267,30 +280,33 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     // ---- per-thread staging sources of the current tile (GX rows of X and GW rows of W per slice)
     const int srow = tid / CPR;
     const int chunk = (tid % CPR) ^ (srow & 7);
-    const bf16_t* xp[GX];
-    const bf16_t* wp[GW];
+    // 32-bit byte offsets from the (wave-uniform) tensor bases: the DMA then takes the base in SGPRs and one offset
+    // VGPR per lane instead of a 64-bit address pair (the launcher checks that both tensors span < 4 GiB)
+    uint32_t xo[GX], wo[GW];
     auto set_sources = [&](int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < GX; ++i) {
             int m = m0 + srow + RPR * i;
             m = m < a.M ? m : a.M - 1;
-            xp[i] = a.X + (int64_t)(m / a.x_rpb) * a.x_bs + (int64_t)(m % a.x_rpb) * a.x_rs + chunk * 8;
+            xo[i] = (uint32_t)(((int64_t)(m / a.x_rpb) * a.x_bs + (int64_t)(m % a.x_rpb) * a.x_rs + chunk * 8) * 2);
         }
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
             int n = n0 + srow + RPR * i;
             n = n < a.N ? n : a.N - 1;
-            wp[i] = a.W + (int64_t)n * a.K + chunk * 8;
+            wo[i] = (uint32_t)(((int64_t)n * a.K + chunk * 8) * 2);
         }
     };
     const int wave_lds = wave * 1024;
     auto stage = [&](int kt, int slot) {
         char* sb = smem + slot * STAGE;
-        const int k0 = kt * BK;
+        // readfirstlane keeps the bases opaque scalars, so that every DMA takes the SGPR-base + VGPR-offset form
+        const char* xb = uniform_ptr(reinterpret_cast<const char*>(a.X) + (size_t)kt * (BK * 2));
+        const char* wb = uniform_ptr(reinterpret_cast<const char*>(a.W) + (size_t)kt * (BK * 2));
 #pragma unroll
-        for (int i = 0; i < GX; ++i) glds16(xp[i] + k0, sb + i * (NTHR * 16) + wave_lds);
+        for (int i = 0; i < GX; ++i) glds16(xb + xo[i], sb + i * (NTHR * 16) + wave_lds);
 #pragma unroll
-        for (int i = 0; i < GW; ++i) glds16(wp[i] + k0, sb + XOPER + i * (NTHR * 16) + wave_lds);
+        for (int i = 0; i < GW; ++i) glds16(wb + wo[i], sb + XOPER + i * (NTHR * 16) + wave_lds);
     };
 
     f32x4 acc[4][MT];  // [nt][mt]
@@ -300,90 +316,155 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    const int x_off = (wm * (16 * MT) + frow) * RB;
-    const int w_off = XOPER + (wn * 64 + frow) * RB;
-    auto compute = [&](const char* sb) {
+    constexpr int HB = MT / 2;  // 16-row X fragments per half of the wave's rows
+
+    // ---- fragment stream.  A slice is multiplied in four phases (k-step ks, row half mh) of 4 x HB MFMAs:
+    //   A = (0, 0), B = (0, 1), C = (1, 0), D = (1, 1).  Fragments live in W[4] (one per 16 columns), X[HB] (even
+    // phases) and Xn[HB] (odd phases) and are read one phase ahead of their use, by hand-written ds_read_b128 with
+    // counted lgkmcnt waits (LDS returns in order), each register set reloaded as soon as its last MFMA has issued:
+    //   even phase: X and W[0] ready at its start (lgkmcnt(3): W[1..3] may still be on their way), W[g] before group
+    //               g; reads Xn (same slot, same k-step) behind group 0;
+    //   odd phase:  Xn ready at its start; reads X for the next even phase behind group 0 and W[g] behind group g.
+    // Phase D holds the slice's only barrier: after it every wave has finished READING slice j (slot free: slice
+    // j + 2 is staged into it right there) and slice j + 1 has landed for everyone (its fragments are read from the
+    // other slot during D).  With the compiler's own schedule (reads, lgkmcnt(0), 16 MFMAs, four times per slice,
+    // both waves of a SIMD waiting on the LDS together after the barrier) a slice took 3.1-3.2 k cycles.
+    uint32_t xa[2], wa[2];  // slot-0 LDS addresses of this lane's fragment rows, per k-step
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fq) ^ (frow & 7)) << 4;
-            bf16x8 wf[4];
+    for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((ks * 4 + fq) ^ (frow & 7)) << 4;
+        xa[ks] = lds_addr32(smem) + (wm * (16 * MT) + frow) * RB + coff;
+        wa[ks] = lds_addr32(smem) + XOPER + (wn * 64 + frow) * RB + coff;
+    }
+    u32x4 W[4], X[HB], Xn[HB];
+    auto tie = [](u32x4& r) { asm volatile("" : "+v"(r)); };
+    auto group = [&](auto gc, auto mhc, u32x4 (&xs)[HB]) {
+        constexpr int g = decltype(gc)::value, mh = decltype(mhc)::value;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(sb + w_off + t * 16 * RB + coff);
+        for (int t = 0; t < HB; ++t)
+            acc[g][mh * HB + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, W[g]), __builtin_bit_cast(bf16x8, xs[t]), acc[g][mh * HB + t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_x = [&](u32x4 (&dst)[HB], uint32_t base, auto mhc) {
+        constexpr int mh = decltype(mhc)::value;
+        static_for<HB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            dst[t] = lds_read16<(mh * HB + t) * 16 * RB>(base);
+        });
+    };
+    auto read_w = [&](auto gc, uint32_t base) {
+        constexpr int g = decltype(gc)::value;
+        W[g] = lds_read16<g * 16 * RB>(base);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto even_phase = [&](uint32_t xbase) {  // xbase = xa[ks] + slot offset
+        asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh) {
-                constexpr int HB = MT / 2;
-                bf16x8 xf[HB];
+        for (int t = 0; t < HB; ++t) tie(X[t]);
+        tie(W[0]);
+        group(I0{}, I0{}, X);
+        read_x(Xn, xbase, I1{});
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(HB + 2) : "memory");
+        tie(W[1]);
+        group(I1{}, I0{}, X);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(HB + 1) : "memory");
+        tie(W[2]);
+        group(I2{}, I0{}, X);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(HB) : "memory");
+        tie(W[3]);
+        group(I3{}, I0{}, X);
+    };
+    // `pre` runs between the wait for Xn and the MFMAs (phase D: barrier and staging)
+    auto odd_phase = [&](uint32_t xnext, uint32_t wnext, bool reads, auto&& pre) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int t = 0; t < HB; ++t)
-                    xf[t] = *reinterpret_cast<const bf16x8*>(sb + x_off + (mh * HB + t) * 16 * RB + coff);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int t = 0; t < HB; ++t)
-                        acc[nt][mh * HB + t] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[t], acc[nt][mh * HB + t], 0, 0, 0);
-            }
-        }
+        for (int t = 0; t < HB; ++t) tie(Xn[t]);
+        pre();
+        group(I0{}, I1{}, Xn);
+        if (reads) { read_x(X, xnext, I0{}); read_w(I0{}, wnext); }
+        group(I1{}, I1{}, Xn);
+        if (reads) read_w(I1{}, wnext);
+        group(I2{}, I1{}, Xn);
+        if (reads) read_w(I2{}, wnext);
+        group(I3{}, I1{}, Xn);
+        if (reads) read_w(I3{}, wnext);
+    };
+    auto first_reads = [&](int slot) {  // fragments of phase A of the slice in `slot`
+        const uint32_t so = slot * STAGE;
+        read_x(X, xa[0] + so, I0{});
+        read_w(I0{}, wa[0] + so);
+        read_w(I1{}, wa[0] + so);
+        read_w(I2{}, wa[0] + so);
+        read_w(I3{}, wa[0] + so);
     };
 
     const int nkt = a.K / BK;
-    float bias_lane = 0.f;
     int t = lidx;
     int m0 = (tm_lo + t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
     set_sources(m0, n0);
+    // A tile's bias, one column per lane, goes straight to the epilogue patch by a 4-byte LDS-DMA issued at the start of
+    // the tile: no destination register, so no compiler-placed wait anywhere in the K loop (a register load under a
+    // condition became a select + s_waitcnt vmcnt(0) at the top of EVERY slice; hoisted out of the loop it became a
+    // vmcnt(0) in the loop preheader, behind the previous epilogue's stores).  It has landed by the vmcnt(0) of the
+    // tile's last phase D at the latest.
+    char* const patch = smem + RING + wave * PATCH;
+    auto load_bias = [&](int n_tile) {
+        if (a.bias) {
+            int n = n_tile + wn * 64 + lane;
+            n = n < a.N ? n : a.N - 1;  // columns past N are never stored
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a.bias + n), LDS_PTR(patch), 4, 0, 0);
+        } else {
+            reinterpret_cast<float*>(patch)[lane] = 0.f;
+        }
+    };
+    load_bias(n0);
     PSTAMP(0);
     stage(0, 0);
     stage(1, 1);
-    wait_older<GX + GW>();  // my part of slice 0 ...
+    wait_older<GX + GW>();                   // my part of slice 0 ...
     asm volatile("s_barrier" ::: "memory");  // ... and everyone's
     int slot = 0;
+    first_reads(0);
 #ifdef ASRK_STAMPS
     int tile_no = 0;
 #endif
-    // A tile enters its K loop with slices 0 and 1 staged (slice 1 possibly still in flight).  Slice kt + 1 is
-    // staged at the top of iteration kt >= 1; the last iteration stages slice 0 of the next tile, and slice 1 of
-    // the next tile follows right after the loop, BEFORE the epilogue: a wave's vector-memory operations complete in
-    // issue order, so loads issued behind the epilogue's 16 stores wait until those have drained (measured:
-    // 7.6 k cycles per tile lost in the K loop that followed the epilogue when slice 1 was staged after it).
+    // The K stream runs across tiles: phase D of slice j stages slice j + 2, which near the end of a tile is slice 0
+    // or 1 of the next tile.  Slice 1 of the next tile is therefore issued before the epilogue's stores: a wave's
+    // vector-memory operations complete in issue order, and loads issued behind the 16 stores would wait until those
+    // have drained (measured: 7.6 k cycles per tile).
     while (true) {
         const int tnext = t + wgs_per_xcd;
         const bool has_next = tnext < count;
         int m0n = 0, n0n = 0;
-#pragma nounroll  // also keeps the kt == 0 case from being peeled into a second copy of the body (spills)
+#pragma nounroll
         for (int kt = 0; kt < nkt; ++kt) {
-            // my loads of this slice have landed; after the barrier everyone's have, and everyone has finished
-            // reading the other slot.  Slice 0 needs neither: it was complete for every wave at the barrier in front
-            // of the previous epilogue (or of the loop), and nothing is staged at kt == 0 -- so a wave that leaves
-            // its epilogue early starts on slice 0 while its SIMD partner is still storing.
-            if (kt > 0) wait_all_barrier();
 #ifdef ASRK_STAMPS
             if (kt == 0) { if (tile_no == 0) PSTAMP(1); else if (tile_no == 1) PSTAMP(5); }
 #endif
-            if (kt >= 1 && kt + 1 < nkt) stage(kt + 1, slot ^ 1);
-            if (kt + 1 == nkt) {
-                // this tile's bias, one column per lane (spread to the accumulator layout through the LDS patch in
-                // the epilogue), issued before the next tile's loads so that it is older than all of them
-                const int n = n0 + wn * 64 + lane;
-                bias_lane = (a.bias && n < a.N) ? a.bias[n] : 0.f;
-                if (has_next) {  // the K stream runs on into the next tile
-                    m0n = (tm_lo + tnext / tiles_n) * BM;
-                    n0n = (tnext % tiles_n) * BN;
-                    set_sources(m0n, n0n);
-                    stage(0, slot ^ 1);
+            const uint32_t so = slot * STAGE, so_next = (slot ^ 1) * STAGE;
+            even_phase(xa[0] + so);                                               // A
+            odd_phase(xa[1] + so, wa[1] + so, true, [] {});                       // B
+            even_phase(xa[1] + so);                                               // C
+            odd_phase(xa[0] + so_next, wa[0] + so_next, kt + 1 < nkt, [&] {      // D
+                wait_all_barrier();
+                if (kt + 2 < nkt) {
+                    stage(kt + 2, slot);
+                } else if (has_next) {
+                    if (kt + 2 == nkt) {
+                        m0n = (tm_lo + tnext / tiles_n) * BM;
+                        n0n = (tnext % tiles_n) * BN;
+                        set_sources(m0n, n0n);
+                        stage(0, slot);
+                    } else {
+                        stage(1, slot);
+                    }
                 }
-            }
-            compute(smem + slot * STAGE);
+            });
             slot ^= 1;
-        }
-        // The bias goes to the patch first: the wait for its load (older than every load of the next tile) sits here,
-        // where those have had a whole slice of MFMAs to land, and the epilogue proper then never waits on vmcnt.
-        char* const patch = smem + RING + wave * PATCH;
-        reinterpret_cast<float*>(patch)[lane] = bias_lane;
-        if (has_next) {
-            // slice 0 of the next tile has landed; once everyone has finished reading the slot of the last slice,
-            // slice 1 of the next tile goes there
-            wait_all_barrier();
-            stage(1, slot ^ 1);
         }
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(2);
@@ -401,6 +482,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         t = tnext;
         m0 = m0n;
         n0 = n0n;
+        // slice 0 of this tile was complete for every wave at the barrier of the last phase D: no barrier here, a wave
+        // that leaves its epilogue early starts multiplying while its SIMD partner is still storing
+        first_reads(slot);
+        load_bias(n0);
     }
     PSTAMP(7);
 }
@@ -454,9 +539,19 @@ int dispatch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
 
 }  // namespace
 
+// The kernel addresses X and W by 32-bit byte offsets: both must span less than 4 GiB.
+bool asrk_gemm256p_fits(const GemmArgs& a) {
+    if (a.x_bs < 0 || a.x_rs < 0) return false;
+    const int64_t blocks = (a.M - 1) / a.x_rpb;                               // index of the last row block
+    const int64_t rows = a.x_rpb - 1 < a.M - 1 ? a.x_rpb - 1 : a.M - 1;        // largest row index inside a block
+    const int64_t lim = (int64_t)1 << 31;                                     // in 2-byte elements
+    return blocks * a.x_bs + rows * a.x_rs + a.K < lim && (int64_t)a.N * a.K < lim;
+}
+
 // Arguments are validated by asrk_gemm_launch (asrk_gemm.hip); needs splits == 1, N % 8 == 0, K % 64 == 0.
 int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
     if (a.splits != 1 || (a.N % 8) != 0 || (a.K % BK) != 0 || a.K < 2 * BK) return ASRK_ERR_SHAPE;
+    if (!asrk_gemm256p_fits(a)) return ASRK_ERR_SHAPE;
     // ASRK_GEMM_MT (A/B measurements only): 8 or 6 forces the tile height
     static const int forced = [] { const char* e = getenv("ASRK_GEMM_MT"); return e ? atoi(e) : 0; }();
     const bool use6 = forced == 6 || (forced != 8 && schedule_cost(a, 6) < schedule_cost(a, 8));
