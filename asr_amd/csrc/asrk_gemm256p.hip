@@ -309,6 +309,18 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         for (int i = 0; i < GW; ++i) glds16(wb + wo[i], sb + XOPER + i * (NTHR * 16) + wave_lds);
     };
 
+    // quarter q of a slice's DMA batch: X instructions q, q + 4, ... and W instructions q, q + 4, ...
+    auto stage_part = [&](int kt, int slot, auto qc) {
+        constexpr int q = decltype(qc)::value;
+        char* sb = smem + slot * STAGE;
+        const char* xb = uniform_ptr(reinterpret_cast<const char*>(a.X) + (size_t)kt * (BK * 2));
+        const char* wb = uniform_ptr(reinterpret_cast<const char*>(a.W) + (size_t)kt * (BK * 2));
+#pragma unroll
+        for (int i = q; i < GX; i += 4) glds16(xb + xo[i], sb + i * (NTHR * 16) + wave_lds);
+#pragma unroll
+        for (int i = q; i < GW; i += 4) glds16(wb + wo[i], sb + XOPER + i * (NTHR * 16) + wave_lds);
+    };
+
     f32x4 acc[4][MT];  // [nt][mt]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -379,18 +391,25 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         group(I3{}, I0{}, X);
     };
     // `pre` runs between the wait for Xn and the MFMAs (phase D: barrier and staging)
-    auto odd_phase = [&](uint32_t xnext, uint32_t wnext, bool reads, auto&& pre) {
+    // `pre` runs between the wait for Xn and the MFMAs (phase D: the barrier); `mid(g)` behind MFMA group g (phase D:
+    // a quarter of the next DMA batch each, so that their issue -- 40-75 cycles apiece -- falls under MFMAs in flight
+    // instead of all 8 following the barrier back to back on both waves of the SIMD at once)
+    auto odd_phase = [&](uint32_t xnext, uint32_t wnext, bool reads, auto&& pre, auto&& mid) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < HB; ++t) tie(Xn[t]);
         pre();
         group(I0{}, I1{}, Xn);
+        mid(I0{});
         if (reads) { read_x(X, xnext, I0{}); read_w(I0{}, wnext); }
         group(I1{}, I1{}, Xn);
+        mid(I1{});
         if (reads) read_w(I1{}, wnext);
         group(I2{}, I1{}, Xn);
+        mid(I2{});
         if (reads) read_w(I2{}, wnext);
         group(I3{}, I1{}, Xn);
+        mid(I3{});
         if (reads) read_w(I3{}, wnext);
     };
     auto first_reads = [&](int slot) {  // fragments of phase A of the slice in `slot`
@@ -447,22 +466,23 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
 #endif
             const uint32_t so = slot * STAGE, so_next = (slot ^ 1) * STAGE;
             even_phase(xa[0] + so);                                               // A
-            odd_phase(xa[1] + so, wa[1] + so, true, [] {});                       // B
+            odd_phase(xa[1] + so, wa[1] + so, true, [] {}, [](auto) {});          // B
             even_phase(xa[1] + so);                                               // C
-            odd_phase(xa[0] + so_next, wa[0] + so_next, kt + 1 < nkt, [&] {      // D
-                wait_all_barrier();
-                if (kt + 2 < nkt) {
-                    stage(kt + 2, slot);
-                } else if (has_next) {
-                    if (kt + 2 == nkt) {
-                        m0n = (tm_lo + tnext / tiles_n) * BM;
-                        n0n = (tnext % tiles_n) * BN;
-                        set_sources(m0n, n0n);
-                        stage(0, slot);
-                    } else {
-                        stage(1, slot);
-                    }
+            // D: which slice goes into the slot this one leaves (slice j + 2 of the stream)
+            int st_kt = -1;
+            if (kt + 2 < nkt) {
+                st_kt = kt + 2;
+            } else if (has_next) {
+                st_kt = kt + 2 - nkt;
+                if (st_kt == 0) {
+                    m0n = (tm_lo + tnext / tiles_n) * BM;
+                    n0n = (tnext % tiles_n) * BN;
+                    set_sources(m0n, n0n);
                 }
+            }
+            odd_phase(xa[0] + so_next, wa[0] + so_next, kt + 1 < nkt, [] { wait_all_barrier(); }, [&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (st_kt >= 0) stage_part(st_kt, slot, std::integral_constant<int, g>{});
             });
             slot ^= 1;
         }
