@@ -315,10 +315,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         char* sb = smem + slot * STAGE;
         const char* xb = uniform_ptr(reinterpret_cast<const char*>(a.X) + (size_t)kt * (BK * 2));
         const char* wb = uniform_ptr(reinterpret_cast<const char*>(a.W) + (size_t)kt * (BK * 2));
+        // X first (quarters 0, 1: it comes from further away than W, which the XCD's other tiles keep in L2)
+        if (q < 2) {
 #pragma unroll
-        for (int i = q; i < GX; i += 4) glds16(xb + xo[i], sb + i * (NTHR * 16) + wave_lds);
+            for (int i = q; i < GX; i += 2) glds16(xb + xo[i], sb + i * (NTHR * 16) + wave_lds);
+        } else {
 #pragma unroll
-        for (int i = q; i < GW; i += 4) glds16(wb + wo[i], sb + XOPER + i * (NTHR * 16) + wave_lds);
+            for (int i = q - 2; i < GW; i += 2) glds16(wb + wo[i], sb + XOPER + i * (NTHR * 16) + wave_lds);
+        }
     };
 
     f32x4 acc[4][MT];  // [nt][mt]
