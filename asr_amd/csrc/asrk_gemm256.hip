@@ -339,7 +339,7 @@ int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t
     // ASRK_GEMM_CFG (A/B measurements only): 2 = one tile per workgroup always, 4 = persistent always,
     // 1 = 256x256 BK 32 x 4 stages, 3 = 256x128 BK 32 x 3 stages
     static const int cfg = [] { const char* e = getenv("ASRK_GEMM_CFG"); return e ? atoi(e) : 0; }();
-    if ((cfg == 4 || (cfg == 0 && out_bf16)) && a.K % 64 == 0 && a.K >= 128 && !(gelu && a.dg_pre) && asrk_gemm256p_fits(a)) return asrk_gemm256p_launch(a, gelu, out_bf16, st);
+    if ((cfg == 4 || (cfg == 0 && out_bf16)) && a.K % 64 == 0 && a.K >= 192 && !(gelu && a.dg_pre) && asrk_gemm256p_fits(a)) return asrk_gemm256p_launch(a, gelu, out_bf16, st);
     if (cfg == 1) return dispatch<4, 32, 4>(a, gelu, out_bf16, st);
     if (cfg == 3) return dispatch<2, 32, 3>(a, gelu, out_bf16, st);
     return dispatch<4, 64, 2>(a, gelu, out_bf16, st);

@@ -42,10 +42,12 @@ constexpr int RB = BK * 2;           // bytes per LDS row
 constexpr int CPR = RB / 16;         // 16-byte chunks per row
 constexpr int GW = BN * CPR / NTHR;
 constexpr int RPR = NTHR / CPR;      // rows staged per round of NTHR lanes
-constexpr int STAGE_MAX = (256 + BN) * RB;
-constexpr int RING = 2 * STAGE_MAX;  // the ring is sized for the 256-row tile
-constexpr int PATCH = 4096;          // private epilogue patch per wave
-constexpr int LDS_BYTES = RING + 8 * PATCH;
+constexpr int SLOT = 256 * RB;        // one operand slice of up to 256 rows: 32 KiB
+constexpr int NXS = 3, NWS = 2;      // ring slots of X and of W
+constexpr int WBASE = NXS * SLOT;    // W slots follow the X slots
+constexpr int PATCH = 4096;          // private epilogue patch per wave; the 8 patches alias the free X slot
+constexpr int LDS_BYTES = (NXS + NWS) * SLOT;
+static_assert(8 * PATCH == SLOT, "the epilogue patches fill exactly one X slot");
 static_assert(LDS_BYTES == 163840, "uses all of the CU's LDS");
 
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
@@ -257,12 +259,11 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
 
 template <int MT, int EPI, bool OUT_BF16>
 __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
-    constexpr int BM = 32 * MT;          // 2 waves along m, 16 * MT rows each
-    constexpr int XOPER = BM * RB;       // bytes of the X slice
-    constexpr int STAGE = XOPER + BN * RB;
+    constexpr int BM = 32 * MT;  // 2 waves along m, 16 * MT rows each
     constexpr int GX = BM * CPR / NTHR;
     static_assert(BM * CPR % NTHR == 0 && MT % 2 == 0, "tile height");
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][X slice | W slice] | 8 epilogue patches
+    // LDS: X slots 0..2 | W slots 0..1.  Slice j of the K stream lives in X slot j % 3 and W slot j % 2.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,19 +278,22 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     const int count = tm_cnt > 0 ? tm_cnt * tiles_n : 0;
     if (lidx >= count) return;
 
-    // ---- per-thread staging sources of the current tile (GX rows of X and GW rows of W per slice)
+    // ---- per-thread DMA sources (GX rows of X and GW rows of W per slice): 32-bit byte offsets from the
+    // (wave-uniform) tensor bases, so the DMA takes the base in SGPRs and one offset VGPR per lane instead of a 64-bit
+    // address pair (the launcher checks that both tensors span < 4 GiB).  X and W switch to the next tile at different
+    // points of the stream, hence two setters.
     const int srow = tid / CPR;
     const int chunk = (tid % CPR) ^ (srow & 7);
-    // 32-bit byte offsets from the (wave-uniform) tensor bases: the DMA then takes the base in SGPRs and one offset
-    // VGPR per lane instead of a 64-bit address pair (the launcher checks that both tensors span < 4 GiB)
     uint32_t xo[GX], wo[GW];
-    auto set_sources = [&](int m0, int n0) {
+    auto set_x = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < GX; ++i) {
             int m = m0 + srow + RPR * i;
             m = m < a.M ? m : a.M - 1;
             xo[i] = (uint32_t)(((int64_t)(m / a.x_rpb) * a.x_bs + (int64_t)(m % a.x_rpb) * a.x_rs + chunk * 8) * 2);
         }
+    };
+    auto set_w = [&](int n0) {
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
             int n = n0 + srow + RPR * i;
@@ -298,32 +302,25 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         }
     };
     const int wave_lds = wave * 1024;
-    auto stage = [&](int kt, int slot) {
-        char* sb = smem + slot * STAGE;
-        // readfirstlane keeps the bases opaque scalars, so that every DMA takes the SGPR-base + VGPR-offset form
+    // half h of the X (W) DMAs of slice kt into X slot xs (W slot ws)
+    auto stage_x = [&](int kt, int xs, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        char* sb = smem + xs * SLOT;
         const char* xb = uniform_ptr(reinterpret_cast<const char*>(a.X) + (size_t)kt * (BK * 2));
+#pragma unroll
+        for (int i = h; i < GX; i += 2) glds16(xb + xo[i], sb + i * (NTHR * 16) + wave_lds);
+    };
+    auto stage_w = [&](int kt, int ws, auto hc) {
+        constexpr int h = decltype(hc)::value;
+        char* sb = smem + WBASE + ws * SLOT;
         const char* wb = uniform_ptr(reinterpret_cast<const char*>(a.W) + (size_t)kt * (BK * 2));
 #pragma unroll
-        for (int i = 0; i < GX; ++i) glds16(xb + xo[i], sb + i * (NTHR * 16) + wave_lds);
-#pragma unroll
-        for (int i = 0; i < GW; ++i) glds16(wb + wo[i], sb + XOPER + i * (NTHR * 16) + wave_lds);
+        for (int i = h; i < GW; i += 2) glds16(wb + wo[i], sb + i * (NTHR * 16) + wave_lds);
     };
-
-    // quarter q of a slice's DMA batch: X instructions q, q + 4, ... and W instructions q, q + 4, ...
-    auto stage_part = [&](int kt, int slot, auto qc) {
-        constexpr int q = decltype(qc)::value;
-        char* sb = smem + slot * STAGE;
-        const char* xb = uniform_ptr(reinterpret_cast<const char*>(a.X) + (size_t)kt * (BK * 2));
-        const char* wb = uniform_ptr(reinterpret_cast<const char*>(a.W) + (size_t)kt * (BK * 2));
-        // X first (quarters 0, 1: it comes from further away than W, which the XCD's other tiles keep in L2)
-        if (q < 2) {
-#pragma unroll
-            for (int i = q; i < GX; i += 2) glds16(xb + xo[i], sb + i * (NTHR * 16) + wave_lds);
-        } else {
-#pragma unroll
-            for (int i = q - 2; i < GW; i += 2) glds16(wb + wo[i], sb + XOPER + i * (NTHR * 16) + wave_lds);
-        }
-    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
 
     f32x4 acc[4][MT];  // [nt][mt]
 #pragma unroll
@@ -341,25 +338,23 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     //   even phase: X and W[0] ready at its start (lgkmcnt(3): W[1..3] may still be on their way), W[g] before group
     //               g; reads Xn (same slot, same k-step) behind group 0;
     //   odd phase:  Xn ready at its start; reads X for the next even phase behind group 0 and W[g] behind group g.
-    // Phase D holds the slice's only barrier: after it every wave has finished READING slice j (slot free: slice
-    // j + 2 is staged into it right there) and slice j + 1 has landed for everyone (its fragments are read from the
-    // other slot during D).  With the compiler's own schedule (reads, lgkmcnt(0), 16 MFMAs, four times per slice,
-    // both waves of a SIMD waiting on the LDS together after the barrier) a slice took 3.1-3.2 k cycles.
+    // Phase D holds the slice's only barrier: after it every wave has finished READING slice j (its slots are free)
+    // and slice j + 1 has landed for everyone (its fragments are read from the next slots during D).
     uint32_t xa[2], wa[2];  // slot-0 LDS addresses of this lane's fragment rows, per k-step
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int coff = ((ks * 4 + fq) ^ (frow & 7)) << 4;
         xa[ks] = lds_addr32(smem) + (wm * (16 * MT) + frow) * RB + coff;
-        wa[ks] = lds_addr32(smem) + XOPER + (wn * 64 + frow) * RB + coff;
+        wa[ks] = lds_addr32(smem) + WBASE + (wn * 64 + frow) * RB + coff;
     }
     u32x4 W[4], X[HB], Xn[HB];
     auto tie = [](u32x4& r) { asm volatile("" : "+v"(r)); };
-    auto group = [&](auto gc, auto mhc, u32x4 (&xs)[HB]) {
+    auto group = [&](auto gc, auto mhc, u32x4 (&xs_)[HB]) {
         constexpr int g = decltype(gc)::value, mh = decltype(mhc)::value;
 #pragma unroll
         for (int t = 0; t < HB; ++t)
             acc[g][mh * HB + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, W[g]), __builtin_bit_cast(bf16x8, xs[t]), acc[g][mh * HB + t], 0, 0, 0);
+                __builtin_bit_cast(bf16x8, W[g]), __builtin_bit_cast(bf16x8, xs_[t]), acc[g][mh * HB + t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto read_x = [&](u32x4 (&dst)[HB], uint32_t base, auto mhc) {
@@ -373,11 +368,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         constexpr int g = decltype(gc)::value;
         W[g] = lds_read16<g * 16 * RB>(base);
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    auto even_phase = [&](uint32_t xbase) {  // xbase = xa[ks] + slot offset
+    auto even_phase = [&](uint32_t xbase) {  // xbase = xa[ks] + X slot offset
         asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < HB; ++t) tie(X[t]);
@@ -394,10 +385,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         tie(W[3]);
         group(I3{}, I0{}, X);
     };
-    // `pre` runs between the wait for Xn and the MFMAs (phase D: barrier and staging)
     // `pre` runs between the wait for Xn and the MFMAs (phase D: the barrier); `mid(g)` behind MFMA group g (phase D:
-    // a quarter of the next DMA batch each, so that their issue -- 40-75 cycles apiece -- falls under MFMAs in flight
-    // instead of all 8 following the barrier back to back on both waves of the SIMD at once)
+    // part of the next DMA batch each, so that their issue -- 40-75 cycles apiece -- falls under MFMAs in flight
+    // instead of all of them following the barrier back to back on both waves of the SIMD at once)
     auto odd_phase = [&](uint32_t xnext, uint32_t wnext, bool reads, auto&& pre, auto&& mid) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -416,79 +406,110 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         mid(I3{});
         if (reads) read_w(I3{}, wnext);
     };
-    auto first_reads = [&](int slot) {  // fragments of phase A of the slice in `slot`
-        const uint32_t so = slot * STAGE;
-        read_x(X, xa[0] + so, I0{});
-        read_w(I0{}, wa[0] + so);
-        read_w(I1{}, wa[0] + so);
-        read_w(I2{}, wa[0] + so);
-        read_w(I3{}, wa[0] + so);
+    auto first_reads = [&](int xs, int ws) {  // fragments of phase A of the slice in X slot xs / W slot ws
+        read_x(X, xa[0] + xs * SLOT, I0{});
+        read_w(I0{}, wa[0] + ws * SLOT);
+        read_w(I1{}, wa[0] + ws * SLOT);
+        read_w(I2{}, wa[0] + ws * SLOT);
+        read_w(I3{}, wa[0] + ws * SLOT);
     };
 
-    const int nkt = a.K / BK;
+    const int nkt = a.K / BK;  // >= 3 (launcher)
     int t = lidx;
     int m0 = (tm_lo + t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-    set_sources(m0, n0);
-    // A tile's bias, one column per lane, goes straight to the epilogue patch by a 4-byte LDS-DMA issued at the start of
-    // the tile: no destination register, so no compiler-placed wait anywhere in the K loop (a register load under a
-    // condition became a select + s_waitcnt vmcnt(0) at the top of EVERY slice; hoisted out of the loop it became a
-    // vmcnt(0) in the loop preheader, behind the previous epilogue's stores).  It has landed by the vmcnt(0) of the
-    // tile's last phase D at the latest.
-    char* const patch = smem + RING + wave * PATCH;
+    set_x(m0);
+    set_w(n0);
+    // A tile's bias, one column per lane: loaded by asm at the start of the tile into a register the compiler knows
+    // nothing about (a compiler-visible load inside the K loop became a select + s_waitcnt vmcnt(0) at the top of EVERY
+    // slice; hoisted out of it, a vmcnt(0) in the loop preheader behind the previous epilogue's stores).  It is older
+    // than everything else the tile issues, so every counted wait of the K loop covers it.
+    float bias_reg = 0.f;
     auto load_bias = [&](int n_tile) {
+        bias_reg = 0.f;
         if (a.bias) {
             int n = n_tile + wn * 64 + lane;
             n = n < a.N ? n : a.N - 1;  // columns past N are never stored
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a.bias + n), LDS_PTR(patch), 4, 0, 0);
-        } else {
-            reinterpret_cast<float*>(patch)[lane] = 0.f;
+            const float* p = a.bias + n;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(bias_reg) : "v"(p) : "memory");
         }
     };
     load_bias(n0);
     PSTAMP(0);
-    stage(0, 0);
-    stage(1, 1);
-    wait_older<GX + GW>();                   // my part of slice 0 ...
+    // prologue: slices 0, 1 and X of slice 2; the order X0 W0 X1 W1 X2 is the order of the stream
+    stage_x(0, 0, I0{}); stage_x(0, 0, I1{});
+    stage_w(0, 0, I0{}); stage_w(0, 0, I1{});
+    stage_x(1, 1, I0{}); stage_x(1, 1, I1{});
+    stage_w(1, 1, I0{}); stage_w(1, 1, I1{});
+    stage_x(2, 2, I0{}); stage_x(2, 2, I1{});
+    wait_older<2 * GX + GW>();               // my part of slice 0 ...
     asm volatile("s_barrier" ::: "memory");  // ... and everyone's
-    int slot = 0;
-    first_reads(0);
+    int xs = 0, ws = 0;                      // slots of the slice being multiplied
+    bool x_behind = true;                    // the youngest GX DMAs in flight are an X batch for the slice after next
+    first_reads(0, 0);
 #ifdef ASRK_STAMPS
     int tile_no = 0;
 #endif
-    // The K stream runs across tiles: phase D of slice j stages slice j + 2, which near the end of a tile is slice 0
-    // or 1 of the next tile.  Slice 1 of the next tile is therefore issued before the epilogue's stores: a wave's
-    // vector-memory operations complete in issue order, and loads issued behind the 16 stores would wait until those
-    // have drained (measured: 7.6 k cycles per tile).
+    // The K stream runs across tiles.  Phase D of slice j (kt of this tile) stages W of slice j + 2 into the W slot it
+    // leaves and X of slice j + 3 into the X slot it leaves: W comes from the XCD's L2 and one slice of lead covers it;
+    // X comes from the memory-side cache or from HBM (fc2: 590 MB, never resident -- 3.1 k cycles per slice with one
+    // slice of lead against 2.07 k, the MFMA bound, with X resident), hence the third X slot.  Near the end of a tile
+    // those slices belong to the next tile.  The epilogue patches alias the X slot the tile's last slice leaves; the X
+    // batch that would go there is issued one slice later, at the first barrier of the next tile.
     while (true) {
         const int tnext = t + wgs_per_xcd;
         const bool has_next = tnext < count;
-        int m0n = 0, n0n = 0;
+        const int m0n = has_next ? (tm_lo + tnext / tiles_n) * BM : 0;
+        const int n0n = has_next ? (tnext % tiles_n) * BN : 0;
+        const bool late_x = t != lidx;  // not the first tile: X of slice 2 is still to be staged (see above)
 #pragma nounroll
         for (int kt = 0; kt < nkt; ++kt) {
 #ifdef ASRK_STAMPS
             if (kt == 0) { if (tile_no == 0) PSTAMP(1); else if (tile_no == 1) PSTAMP(5); }
 #endif
-            const uint32_t so = slot * STAGE, so_next = (slot ^ 1) * STAGE;
-            even_phase(xa[0] + so);                                               // A
-            odd_phase(xa[1] + so, wa[1] + so, true, [] {}, [](auto) {});          // B
-            even_phase(xa[1] + so);                                               // C
-            // D: which slice goes into the slot this one leaves (slice j + 2 of the stream)
-            int st_kt = -1;
-            if (kt + 2 < nkt) {
-                st_kt = kt + 2;
-            } else if (has_next) {
-                st_kt = kt + 2 - nkt;
-                if (st_kt == 0) {
-                    m0n = (tm_lo + tnext / tiles_n) * BM;
-                    n0n = (tnext % tiles_n) * BN;
-                    set_sources(m0n, n0n);
-                }
-            }
-            odd_phase(xa[0] + so_next, wa[0] + so_next, kt + 1 < nkt, [] { wait_all_barrier(); }, [&](auto gc) {
+            const int xs1 = xs == NXS - 1 ? 0 : xs + 1;
+            const uint32_t xso = xs * SLOT, wso = ws * SLOT;
+            even_phase(xa[0] + xso);                                                    // A
+            odd_phase(xa[1] + xso, wa[1] + wso, true, [] {}, [](auto) {});              // B
+            even_phase(xa[1] + xso);                                                    // C
+            // D: W of slice j + 2 -> W slot ws; X of slice j + 3 -> X slot xs (not behind a tile's last slice: the
+            // epilogue patches go there); behind the first slice of a later tile also the X batch left out then
+            int w_kt = -1, x_kt = -1;
+            if (kt + 2 < nkt) w_kt = kt + 2; else if (has_next) w_kt = kt + 2 - nkt;
+            if (kt + 3 < nkt) x_kt = kt + 3; else if (has_next && kt + 1 < nkt) x_kt = kt + 3 - nkt;
+            const bool extra_x = late_x && kt == 0;
+            const int xs_prev = xs == 0 ? NXS - 1 : xs - 1;
+            const bool xb_now = x_behind;
+            odd_phase(xa[0] + xs1 * SLOT, wa[0] + (ws ^ 1) * SLOT, kt + 1 < nkt,
+                      [&] {
+                          // slice j + 1 complete: everything but the X batch issued last, if there is one
+                          if (xb_now) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GX) : "memory");
+                          else wait_all_barrier();
+                      },
+                      [&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                if (st_kt >= 0) stage_part(st_kt, slot, std::integral_constant<int, g>{});
+                if (g == 0) {
+                    if (extra_x) { stage_x(2, xs_prev, I0{}); stage_x(2, xs_prev, I1{}); }
+                    // the sources switch to the next tile where its first slice is staged (at K = 192 the X switch and
+                    // the late X batch of this tile fall into the same phase: the late batch goes first)
+                    if (has_next && kt + 2 == nkt) set_w(n0n);
+                    if (w_kt >= 0) stage_w(w_kt, ws, I0{});
+                } else if (g == 1) {
+                    if (w_kt >= 0) stage_w(w_kt, ws, I1{});
+                } else if (g == 2) {
+                    if (has_next && kt + 3 == nkt) set_x(m0n);
+                    if (x_kt >= 0) stage_x(x_kt, xs, I0{});
+                } else {
+                    if (x_kt >= 0) stage_x(x_kt, xs, I1{});
+                }
             });
-            slot ^= 1;
+            x_behind = x_kt >= 0;
+            if (kt + 1 < nkt) { xs = xs1; ws ^= 1; }
+        }
+        // xs / ws are still the slots of the last slice: X slot xs holds the patches now
+        char* const patch = smem + xs * SLOT + wave * PATCH;
+        {
+            const uint32_t pa = lds_addr32(patch) + lane * 4;
+            asm volatile("ds_write_b32 %0, %1" ::"v"(pa), "v"(bias_reg) : "memory");
         }
 #ifdef ASRK_STAMPS
         if (tile_no == 0) PSTAMP(2);
@@ -506,9 +527,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         t = tnext;
         m0 = m0n;
         n0 = n0n;
+        xs = xs == NXS - 1 ? 0 : xs + 1;
+        ws ^= 1;
         // slice 0 of this tile was complete for every wave at the barrier of the last phase D: no barrier here, a wave
         // that leaves its epilogue early starts multiplying while its SIMD partner is still storing
-        first_reads(slot);
+        first_reads(xs, ws);
         load_bias(n0);
     }
     PSTAMP(7);
@@ -574,7 +597,7 @@ bool asrk_gemm256p_fits(const GemmArgs& a) {
 
 // Arguments are validated by asrk_gemm_launch (asrk_gemm.hip); needs splits == 1, N % 8 == 0, K % 64 == 0.
 int asrk_gemm256p_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st) {
-    if (a.splits != 1 || (a.N % 8) != 0 || (a.K % BK) != 0 || a.K < 2 * BK) return ASRK_ERR_SHAPE;
+    if (a.splits != 1 || (a.N % 8) != 0 || (a.K % BK) != 0 || a.K < 3 * BK) return ASRK_ERR_SHAPE;
     if (!asrk_gemm256p_fits(a)) return ASRK_ERR_SHAPE;
     // ASRK_GEMM_MT (A/B measurements only): 8 or 6 forces the tile height
     static const int forced = [] { const char* e = getenv("ASRK_GEMM_MT"); return e ? atoi(e) : 0; }();
