@@ -2,16 +2,18 @@
 // asrk_gemm256.hip): one 512-thread workgroup per CU walks a list of tiles, and the K stream never stops
 // at a tile boundary.
 //
-//   * The LDS ring (2 stages x 64 K-columns x (256 + 256) rows = 128 KiB) is treated as one long stream of
-//     K slices: while the last slice of tile i is multiplied, slice 0 of tile i+1 is already being written
-//     into the other slot by global_load_lds, so a tile does not start with an exposed HBM/L2 round trip
-//     (5-8 k cycles of ~56 k per tile in the one-tile-per-workgroup kernel).
-//   * The epilogue therefore cannot borrow the ring.  Each wave transposes its own 128 x 64 block through a
-//     private 4 KiB LDS patch (8 waves x 4 KiB = the 32 KiB the ring leaves free), 16 rows at a time:
-//     accumulator layout in, whole 128-byte (bf16) / 256-byte (fp32) row segments out, 16 B per lane.  A wave's
-//     LDS operations execute in order, so this needs no workgroup barrier at all: the waves drift apart in
-//     the epilogue and meet again at the first barrier of the next tile.
-//   * fp32 residual rows are fetched one 16-row group ahead of the group being stored.
+//   * The LDS (160 KiB) is a ring of K slices that never stops at a tile boundary: three 32 KiB slots for X slices and
+//     two for W slices, filled by global_load_lds.  Phase D of slice j stages W of slice j + 2 and X of slice j + 3 --
+//     slices that near the end of a tile belong to the next tile, so a tile does not start with an exposed memory
+//     round trip and its first loads are issued before the previous epilogue's stores (a wave's vector-memory
+//     operations complete in issue order).
+//   * The epilogue cannot borrow the live ring slots.  Each wave transposes its own 128 x 64 block through a private
+//     4 KiB patch, 16 rows at a time: accumulator layout in, whole 128-byte (bf16) / 256-byte (fp32) row segments out,
+//     16 B per lane.  The 8 patches alias the X slot the tile's last slice has just left (the X batch that would go
+//     there is staged one slice later).  A wave's LDS operations execute in order, so this needs no workgroup barrier:
+//     the waves drift apart in the epilogue and meet again at the first barrier of the next tile.
+//   * The K loop is hand-scheduled: fragments by ds_read_b128 asm one phase ahead with counted lgkmcnt waits, the DMA
+//     batch spread behind the MFMA groups of the barrier phase (see the kernel).
 //
 // Tile order: workgroup b runs on XCD b & 7 (verified with HW_REG_XCC_ID); XCD x owns a contiguous run of
 // m panels and walks its tiles n-fastest, 32 tiles (one per CU of the XCD) at a time, so the 32 concurrent
