@@ -453,8 +453,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
 #endif
     // The K stream runs across tiles.  Phase D of slice j (kt of this tile) stages W of slice j + 2 into the W slot it
     // leaves and X of slice j + 3 into the X slot it leaves: W comes from the XCD's L2 and one slice of lead covers it;
-    // X comes from the memory-side cache or from HBM (fc2: 590 MB, never resident -- 3.1 k cycles per slice with one
-    // slice of lead against 2.07 k, the MFMA bound, with X resident), hence the third X slot.  Near the end of a tile
+    // X comes from the memory-side cache or from HBM, hence the third X slot.  Near the end of a tile
     // those slices belong to the next tile.  The epilogue patches alias the X slot the tile's last slice leaves; the X
     // batch that would go there is issued one slice later, at the first barrier of the next tile.
     while (true) {
