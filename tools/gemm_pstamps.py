@@ -32,6 +32,15 @@ assert lib.asrk_debug_read_pstamps(buf.ctypes.data_as(c_void_p), nb * 8) == 0
 t = buf.astype(np.int64)
 med = lambda v: float(np.median(v))  # noqa: E731
 tiles = ((M + 255) // 256) * ((N + 255) // 256)
+
+
+def _rounds(bm):  # schedule_cost of asrk_gemm256p.hip (256 CUs)
+    tm, tn = (M + bm - 1) // bm, (N + 255) // 256
+    return -(-(((tm + 7) // 8) * tn) // 32)
+
+
+mt6 = os.environ.get("ASRK_GEMM_MT") == "6" or (os.environ.get("ASRK_GEMM_MT") != "8" and _rounds(192) * 0.84 < _rounds(256))
+print(f"tile height chosen by the launcher: {192 if mt6 else 256} rows (a 192-row slice is 3/4 of the MFMA work)")
 print(f"M={M} N={N} K={K} gelu={gelu} f32res={f32res}: {tiles} tiles, {tiles / 256:.2f} per workgroup; shader clocks")
 print(f"  tile 0: load wait {med(t[:, 1] - t[:, 0]):8.0f}   K loop {med(t[:, 2] - t[:, 1]):8.0f}   epilogue {med(t[:, 3] - t[:, 2]):8.0f}")
 print(f"  tile 1: wait at first barrier {med(t[:, 5] - t[:, 3]):8.0f}   K loop + epilogue {med(t[:, 6] - t[:, 5]):8.0f}")
