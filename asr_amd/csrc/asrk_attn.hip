@@ -35,7 +35,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 // from -ref (a 16-register block that changes only when the reference moves) instead of 0, and the per-score
 // multiply-subtract in front of every v_exp_f32 disappears (31 of ~170 vector instructions per key tile).
 template <bool LOG2Q>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int T, int H, int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
     const int tid = threadIdx.x;
