@@ -102,6 +102,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // LDS byte address of a pointer into __shared__ memory (operand of hand-written ds_* instructions)
 __device__ __forceinline__ uint32_t lds_addr32(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(p); }
 
+// A wave-uniform pointer made an opaque scalar (v_readfirstlane of both halves), so that `p + 32-bit lane offset` is
+// addressed as SGPR base + VGPR offset instead of a 64-bit VGPR pair.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
 #define ASRK_CHECK_HIP(expr)                                  \
     do {                                                      \
         hipError_t _e = (expr);                               \

@@ -52,12 +52,6 @@ constexpr int LDS_BYTES = (NXS + NWS) * SLOT;
 static_assert(8 * PATCH == SLOT, "the epilogue patches fill exactly one X slot");
 static_assert(LDS_BYTES == 163840, "uses all of the CU's LDS");
 
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-    const uint64_t v = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-}
-
 __device__ __forceinline__ void wait_all_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
 // waits for everything but this wave's N youngest vector-memory operations
 template <int N>
