@@ -124,6 +124,21 @@ def test_gemm_gelu_epilogue_accuracy(lib, M, out_bf16):
         assert err.max().item() <= 1.5e-6, err.max().item()
 
 
+def test_persistent_gemm_sweep():
+    """The persistent kernel's tile stream over many small shapes (see tests/persistent_gemm_sweep.py), forced by the
+    measurement switches, which are read once per process: hence one child process for the whole sweep."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASRK_GEMM_TILE="256", ASRK_GEMM_CFG="4", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "persistent_gemm_sweep.py")], env=env, capture_output=True,
+                       text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bit-exact" in r.stdout
+
+
 def test_gemm_rejects_bad_shapes(lib):
     x = torch.zeros((64, 96), device="cuda", dtype=torch.bfloat16)
     out = torch.zeros((64, 64), device="cuda")
