@@ -81,7 +81,7 @@ _SIGNATURES = {
     "asrk_profile_read": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int), c_int]),
 }
 
-PROF_GEMM, PROF_ATTENTION, PROF_LOGMEL, PROF_NORM, PROF_SPLICE = 0, 1, 2, 3, 4
+PROF_GEMM, PROF_ATTENTION, PROF_LOGMEL, PROF_NORM, PROF_SPLICE, PROF_GEMM256, PROF_GEMM128 = 0, 1, 2, 3, 4, 5, 6
 
 
 def profile_read(cat: int, reset: bool = True):
@@ -93,13 +93,43 @@ def profile_read(cat: int, reset: bool = True):
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
+_owner_pid = None  # the process that loaded the library (and, through it, initialised HIP)
+
+_FORK_MSG = (
+    "asr_amd was called from a forked child process (pid {pid}, library loaded in pid {owner}): a HIP context does "
+    "not survive fork(), so the MI355X kernels cannot run here.  The reference runs its feature extractor inside "
+    "DataLoader workers (src/train.py:172-180 with dataloader_num_workers 6/16): set dataloader_num_workers=0, or keep "
+    "the workers on the CPU-only host steps (LogMelFeatureExtractor.prepare_host / asr_amd.collate.pack_ragged) and "
+    "run the extractor in the training process through asr_amd.collate.FeaturePrefetcher (INTEGRATION.md, section 2)."
+)
+
+
+def assert_not_forked() -> None:
+    """the wrapper must detect use from a forked DataLoader worker instead of hanging or
+    faulting inside HIP.  Two cases: this process is a fork of the one that loaded the library, or it is a fork of a
+    process that had already initialised torch's GPU runtime (torch tracks that itself)."""
+    pid = os.getpid()
+    if _owner_pid is not None and pid != _owner_pid:
+        raise AsrkError(_FORK_MSG.format(pid=pid, owner=_owner_pid))
+    try:
+        import torch
+
+        bad = torch.cuda._is_in_bad_fork()
+    except Exception:  # torch absent or without that probe: the pid check above is what remains
+        bad = False
+    if bad:
+        raise AsrkError(_FORK_MSG.format(pid=pid, owner="the parent, which had initialised the GPU"))
 
 
 def load() -> ctypes.CDLL:
-    """Load libasrk.so once; raise (never fall back) if it is absent or incomplete."""
-    global _lib
+    """Load libasrk.so once; raise (never fall back) if it is absent or incomplete, or if this is a forked child of
+    the process that loaded it."""
+    global _lib, _owner_pid
     if _lib is not None:
+        if os.getpid() != _owner_pid:
+            assert_not_forked()
         return _lib
+    assert_not_forked()
     if not os.path.exists(LIB_PATH):
         raise AsrkError(
             f"{LIB_PATH} not found: build it with `make -C asr_amd/csrc` (or __graft_entry__.build()). "
@@ -112,7 +142,7 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     if lib.asrk_version() < 100:
         raise AsrkError("libasrk.so is older than this Python package")
-    _lib = lib
+    _lib, _owner_pid = lib, os.getpid()
     return lib
 
 

@@ -24,7 +24,8 @@ from .feature_extraction import BatchFeature, LogMelFeatureExtractor
 
 
 def pack_ragged(clips: Sequence, dtype=np.float32, pin: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(pcm [sum(len)] float32|int16, offsets int64 [B+1]), both pinned when a GPU is present."""
+    """(pcm [sum(len)] float32|int16, offsets int64 [B+1]).  CPU only, so it may run inside forked DataLoader workers;
+    both tensors are pinned when this process has already initialised the GPU (never the case in such a worker)."""
     if dtype not in (np.float32, np.int16):
         raise ValueError("dtype must be numpy float32 or int16")
     arrs = []
@@ -35,7 +36,7 @@ def pack_ragged(clips: Sequence, dtype=np.float32, pin: Optional[bool] = None) -
         if dtype == np.int16 and a.dtype != np.int16:
             raise ValueError("int16 packing needs int16 PCM clips (no silent requantisation)")
         arrs.append(a.astype(dtype, copy=False))
-    pin = torch.cuda.is_available() if pin is None else pin
+    pin = torch.cuda.is_initialized() if pin is None else pin
     lens = np.array([len(a) for a in arrs], dtype=np.int64)
     offsets = torch.empty((len(arrs) + 1,), dtype=torch.int64, pin_memory=pin)
     offsets[0] = 0

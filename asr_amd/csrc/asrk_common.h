@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -108,6 +109,18 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const uint64_t v = (uint64_t)p;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+// Opt a kernel in to `bytes` of dynamic LDS once per kernel and device (`done`: one bit per device, a function-local
+// static of the launcher), instead of a hipFuncSetAttribute call in front of every launch.
+inline int asrk_max_lds_once(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ASRK_ERR_HIP;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return ASRK_OK;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ASRK_ERR_HIP;
+    done.fetch_or(bit, std::memory_order_release);
+    return ASRK_OK;
 }
 
 #define ASRK_CHECK_HIP(expr)                                  \

@@ -142,9 +142,9 @@ int launch(const GemmArgs& a, hipStream_t st) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 4 * TILE_BYTES;
     auto kern = gemm_bf16_kernel<GELU, OUT_BF16>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return ASRK_ERR_HIP;
-    AsrkProfScope prof(ASRK_PROF_GEMM, 2.0 * a.M * a.N * a.K, st);
+    static std::atomic<uint64_t> lds_set{0};
+    if (asrk_max_lds_once((const void*)kern, (int)lds, lds_set) != ASRK_OK) return ASRK_ERR_HIP;
+    AsrkProfScope prof(ASRK_PROF_GEMM128, 2.0 * a.M * a.N * a.K, st);
     hipLaunchKernelGGL(kern, dim3(tiles, a.splits), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
@@ -165,14 +165,20 @@ int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st
     // Tile choice: 256 x 256 tiles (one workgroup per CU) once there are enough of them, 128 x 128 tiles otherwise.
     // Measured crossovers (tools/gemm_bench.py, M swept from 1500 to 96000): the persistent bf16-output kernel wins
     // from about half a tile per CU (141 tiles: 22 us against 28 us; 72 tiles lose), the one-tile-per-workgroup
-    // fp32-output kernel only with several rounds of tiles.  ASRK_GEMM_TILE=128|256 overrides (A/B measurements only).
+    // fp32-output kernel only with several rounds of tiles.
+#ifdef ASRK_DIAG  // diagnostic build only (libasrk_diag.so): ASRK_GEMM_TILE=128|256 forces the tile size
     static const int forced = [] { const char* e = getenv("ASRK_GEMM_TILE"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int forced = 0;
+#endif
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const long min_tiles = out_bf16 ? 136 : 512;
     // a ragged last n-tile is fine while at least 7/8 of the tiles' columns are real (N = 960: 93.75 %)
     const long n_cover = (long)((a.N + 255) / 256) * 256;
+    // the 256-tile kernels have no residual add in their bf16 epilogues (no caller on the path combines the two: the
+    // residual stream is fp32); that combination stays on the 128-tile kernel, whose epilogue adds it
     const bool big = a.splits == 1 && (forced == 256 || (forced == 0 && tiles256 >= min_tiles && 8L * a.N >= 7L * n_cover)) &&
-                     (a.N % 8) == 0;
+                     (a.N % 8) == 0 && !(a.res && out_bf16);
     if (big) return asrk_gemm256_launch(a, gelu, out_bf16, st);
     if (gelu) return out_bf16 ? launch<true, true>(a, st) : launch<true, false>(a, st);
     return out_bf16 ? launch<false, true>(a, st) : launch<false, false>(a, st);

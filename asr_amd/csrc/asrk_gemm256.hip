@@ -302,12 +302,15 @@ int launch(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     constexpr int BN = 64 * WN;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    static const int forced = [] { const char* e = getenv("ASRK_GEMM_NSPLIT"); return e ? atoi(e) : 0; }();
     int ns = 1;
+    a.skew = 0;
+#ifdef ASRK_DIAG  // diagnostic build only: XCD n-splits and start-up skew (both measured, neither kept: DESIGN.md 4.2)
+    static const int forced = [] { const char* e = getenv("ASRK_GEMM_NSPLIT"); return e ? atoi(e) : 0; }();
     if (forced > 0 && (forced == 1 || forced == 2 || forced == 4 || forced == 8) && tiles_n % forced == 0) ns = forced;
-    a.nsplit = ns;
     static const int skew = [] { const char* e = getenv("ASRK_GEMM_SKEW"); return e ? atoi(e) : 0; }();
     a.skew = skew;
+#endif
+    a.nsplit = ns;
     const int tm_per = (tiles_m + 8 / ns - 1) / (8 / ns);
     const int tiles = 8 * tm_per * (tiles_n / ns);
     constexpr size_t ring = (size_t)NSTAGE * (256 + BN) * BK * 2;
@@ -316,9 +319,9 @@ int launch(const GemmArgs& a_in, hipStream_t st) {
     constexpr size_t lds = ring > ep ? ring : ep;
     static_assert(lds <= (WN == 4 ? 163840 : 81920), "LDS budget");
     auto kern = gemm256_kernel<WN, BK, NSTAGE, GELU, OUT_BF16>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return ASRK_ERR_HIP;
-    AsrkProfScope prof(ASRK_PROF_GEMM, 2.0 * a.M * a.N * a.K, st);
+    static std::atomic<uint64_t> lds_set{0};
+    if (asrk_max_lds_once((const void*)kern, (int)lds, lds_set) != ASRK_OK) return ASRK_ERR_HIP;
+    AsrkProfScope prof(ASRK_PROF_GEMM256, 2.0 * a.M * a.N * a.K, st);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(128 * WN), lds, st, a);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
@@ -336,11 +339,16 @@ int asrk_gemm256_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t
     if (a.splits != 1 || (a.N % 8) != 0) return ASRK_ERR_SHAPE;
     // Default: bf16 outputs go to the persistent kernel (asrk_gemm256p.hip), fp32 outputs (+ residual) to the
     // one-tile-per-workgroup kernel below, whose two-pass epilogue has room for a deeper residual prefetch.
-    // ASRK_GEMM_CFG (A/B measurements only): 2 = one tile per workgroup always, 4 = persistent always,
-    // 1 = 256x256 BK 32 x 4 stages, 3 = 256x128 BK 32 x 3 stages
+#ifdef ASRK_DIAG
+    // diagnostic build only, ASRK_GEMM_CFG: 2 = one tile per workgroup always, 4 = persistent always,
+    // 1 = 256x256 BK 32 x 4 stages, 3 = 256x128 BK 32 x 3 stages (variants measured and not kept: DESIGN.md 4.2)
     static const int cfg = [] { const char* e = getenv("ASRK_GEMM_CFG"); return e ? atoi(e) : 0; }();
-    if ((cfg == 4 || (cfg == 0 && out_bf16)) && a.K % 64 == 0 && a.K >= 192 && !(gelu && a.dg_pre) && asrk_gemm256p_fits(a)) return asrk_gemm256p_launch(a, gelu, out_bf16, st);
     if (cfg == 1) return dispatch<4, 32, 4>(a, gelu, out_bf16, st);
     if (cfg == 3) return dispatch<2, 32, 3>(a, gelu, out_bf16, st);
+#else
+    constexpr int cfg = 0;
+#endif
+    if ((cfg == 4 || (cfg == 0 && out_bf16)) && a.K % 64 == 0 && a.K >= 192 && !(gelu && a.dg_pre) && asrk_gemm256p_fits(a))
+        return asrk_gemm256p_launch(a, gelu, out_bf16, st);
     return dispatch<4, 64, 2>(a, gelu, out_bf16, st);
 }

@@ -202,8 +202,8 @@ extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, 
     const int n_frames = n_samples / HOP;
     if (n_frames < 1 || B > 65535) return ASRK_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    ASRK_CHECK_HIP(hipFuncSetAttribute((const void*)logmel_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)TILE_LDS_BYTES));
+    static std::atomic<uint64_t> lds_set{0};
+    if (asrk_max_lds_once((const void*)logmel_tile_kernel, (int)TILE_LDS_BYTES, lds_set) != ASRK_OK) return ASRK_ERR_HIP;
     ASRK_CHECK_HIP(hipMemsetAsync(clip_max_ws, 0, (size_t)B * 4, st));
     // algorithmic bytes: read the waveform once, write the features once
     AsrkProfScope prof(ASRK_PROF_LOGMEL, (double)B * ((double)n_samples * 4 + (double)plan->n_mels * n_frames * 4), st);

@@ -108,12 +108,16 @@ class LogMelFeatureExtractor:
     # ------------------------------------------------------------------ device plumbing
     def _device(self, device) -> torch.device:
         dev = torch.device(device) if device is not None else self.device
-        if dev is None or dev.type == "cpu":
-            # HF defaults to device="cpu"; the drop-in has no CPU arithmetic, so "cpu" means
-            # "use the current GPU" (results come back as GPU tensors or numpy arrays).
-            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
-        if dev is None or not torch.cuda.is_available():
+        if dev is not None and dev.type != "cuda":
+            # HF's `device="cpu"` asks for CPU arithmetic and CPU tensors; this drop-in has neither, and quietly running
+            # on a GPU instead would surprise the caller.  The reference's call sites never pass `device`.
+            raise _lib.AsrkError(
+                f"LogMelFeatureExtractor computes on a ROCm GPU only (device={str(dev)!r} requested): pass device=None or "
+                "'cuda[:i]', and use return_tensors='np' for host arrays.  There is no CPU fallback.")
+        if not torch.cuda.is_available():
             raise _lib.AsrkError("LogMelFeatureExtractor needs a ROCm GPU: there is no CPU fallback")
+        if dev is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         return dev
@@ -132,6 +136,7 @@ class LogMelFeatureExtractor:
 
     def extract_from_device(self, wave: torch.Tensor) -> torch.Tensor:
         """wave: CUDA float32 [B, n_samples] (padded) -> CUDA float32 [B, n_mels, n_samples // 160]."""
+        _lib.assert_not_forked()
         if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_cuda:
             raise ValueError("expected a CUDA float32 tensor of shape [batch, n_samples]")
         wave = wave.contiguous()
@@ -164,6 +169,7 @@ class LogMelFeatureExtractor:
             return_attention_mask = self.return_attention_mask
         if str(return_tensors) not in ("pt", "np", "None"):
             raise ValueError("return_tensors must be 'pt', 'np' or None")
+        _lib.assert_not_forked()  # DataLoader workers: fail with the num_workers=0 / FeaturePrefetcher guidance, not inside HIP
 
         if isinstance(raw_speech, torch.Tensor) and raw_speech.is_cuda:  # on-device collate path
             if raw_speech.dim() == 1:
@@ -179,9 +185,9 @@ class LogMelFeatureExtractor:
         if isinstance(raw_speech, torch.Tensor):
             raw_speech = raw_speech.numpy()
 
+        dev = self._device(device)
         host, lengths, target = self.prepare_host(raw_speech, truncation=truncation, pad_to_multiple_of=pad_to_multiple_of,
                                                    padding=padding, max_length=max_length)
-        dev = self._device(device)
         with torch.cuda.device(dev):
             wave = host.to(dev, non_blocking=True)
             feats = self.extract_from_device(wave)
@@ -194,7 +200,9 @@ class LogMelFeatureExtractor:
     def prepare_host(self, raw_speech, truncation: bool = True, pad_to_multiple_of: Optional[int] = None,
                      padding: Optional[str] = "max_length", max_length: Optional[int] = None):
         """Batching, truncation and right-padding of HF __call__ (:278-307; sequence_utils.py:187-220,
-        296-337).  Returns (float32 tensor [B, target], pinned when a GPU is present; lengths; target)."""
+        296-337).  Returns (float32 tensor [B, target]; lengths; target).  The tensor is pinned when this process has
+        already initialised the GPU; a DataLoader worker (no GPU use allowed there) gets pageable memory, so this
+        step stays usable inside forked workers."""
         is_batched_numpy = isinstance(raw_speech, np.ndarray) and raw_speech.ndim > 1
         if is_batched_numpy and raw_speech.ndim > 2:
             raise ValueError(f"Only mono-channel audio is supported for input to {self}")
@@ -218,7 +226,7 @@ class LogMelFeatureExtractor:
         else:
             raise ValueError("padding must be 'max_length' or 'longest': the device kernel works on one dense batch")
         B = len(clips)
-        host = torch.empty((B, target), dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        host = torch.empty((B, target), dtype=torch.float32, pin_memory=torch.cuda.is_initialized())
         host_np = host.numpy()
         lengths = np.empty((B,), dtype=np.int64)
         for i, c in enumerate(clips):

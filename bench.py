@@ -4,10 +4,13 @@
     python bench.py [--gpus N --steps K --warmup W] [--workload pipeline-small|pipeline-large|train-large|logmel|splice]
 
 One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio that is already
-resident in HBM.  With N > 1 the driver launches one rank per GPU through torch.distributed.run;
-every rank processes its own batch (clips are independent: weak scaling, no data-path
-collective), the ranks meet at a barrier on both sides of the timed region and the slowest rank's
-time is used.  Rank 0 prints ONE JSON line.
+resident in HBM.  With N > 1 there is one rank per GPU: either the driver starts them through
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- when
+`--gpus N` is given and WORLD_SIZE is not set -- this script starts N fresh child processes itself
+BEFORE it touches the GPU (launch_ranks below) and relays rank 0's line.  Every rank processes its
+own batch (clips are independent: weak scaling, no data-path collective), the ranks meet at a
+barrier on both sides of the timed region and the slowest rank's time is used.  Rank 0 prints ONE
+JSON line.
 
 Workloads (BASELINE.json configs):
   pipeline-small  (default) 64 x 30 s per GPU, whisper-small dims (d768 L12 H12 ffn3072, 80 mel),
@@ -18,10 +21,14 @@ Workloads (BASELINE.json configs):
                   one flat RCCL all-reduce of the projector gradients per step
   logmel          256 x 30 s per GPU, front-end only (configs[1]), HBM-bound
   splice          SURVEY 8(f2): the embed splice of ASRModel.forward alone, 64 samples (HBM-bound copy)
+  stub            no GPU: a small CPU matmul per step over gloo; exists so that the launcher, the barriers and the
+                  max-over-ranks timing can be tested at world size 2 without a GPU (tests/test_bench_launcher.py)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,6 +51,7 @@ WORKLOADS = {
     # the embed splice of ASRModel.forward, 64 samples x (64 text tokens + 1500 audio
     # positions) x 960 (SmolLM2-360M width), bf16 like the decoder; HBM-bound copy
     "splice": dict(batch=64, text_len=64, text_dim=960),
+    "stub": dict(batch=4),
 }
 
 
@@ -85,14 +93,25 @@ def seeded_models(w, device):
 
 
 def cpu_baseline(wname, w):
-    """The CPU oracle (a port of the reference path, see oracle/) timed on this host's cores on a
-    bounded sample of the same workload."""
+    """The CPU oracle (a port of the reference path, see oracle/) timed on this host's cores on a bounded sample of
+    the same workload, at SURVEY.md section 8(d)'s sizes: front-end 16 clips, encoder + projector 4 clips fp32
+    (1 clip at the large-v3 dimensions, whose forward is 6.5x the work), one warm-up and three timed repetitions,
+    median reported."""
     from oracle import encoder as oe
     from oracle import logmel as ol
     from oracle import projector as op
 
     cores = torch.get_num_threads()
     rng = np.random.default_rng(1234)
+
+    def timed(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
     if wname == "splice":
         from oracle import splice as osp
 
@@ -103,22 +122,17 @@ def cpu_baseline(wname, w):
         ids[:, 5] = 49153
         labels = rng.integers(0, 49000, size=(n, Lt), dtype=np.int64)
         osp.splice(text, audio, ids, labels, 49153)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            osp.splice(text, audio, ids, labels, 49153)
-        dt = (time.perf_counter() - t0) / 5
+        dt = timed(lambda: osp.splice(text, audio, ids, labels, 49153), reps=5)
         return dict(value=n * 30.0 / dt, unit="audio-sec/sec", cores=1, kind="port",
-                    sample=f"{n} samples x 5 reps, NumPy oracle splice (fp32, single thread)")
+                    sample=f"{n} samples, median of 5, NumPy oracle splice (fp32, single thread)")
     if wname == "logmel":
-        n = 8
+        n = 16
         wave = np.clip(0.1 * rng.standard_normal((n, 480000), dtype=np.float32), -1, 1)
         ol.log_mel(wave[:1], w["n_mels"])
-        t0 = time.perf_counter()
-        ol.log_mel(wave, w["n_mels"])
-        dt = time.perf_counter() - t0
+        dt = timed(lambda: ol.log_mel(wave, w["n_mels"]))
         return dict(value=n * 30.0 / dt, unit="audio-sec/sec", cores=1, kind="port",
-                    sample=f"{n} x 30 s clips, numpy/scipy oracle log-mel (single thread)")
-    n = 2 if w["d_model"] <= 768 else 1
+                    sample=f"{n} x 30 s clips, 1 warm-up + median of 3, numpy/scipy oracle log-mel (single thread)")
+    n = 4 if w["d_model"] <= 768 else 1
     wave = np.clip(0.1 * rng.standard_normal((n, 480000), dtype=np.float32), -1, 1)
     tsd = {}
     g = torch.Generator().manual_seed(0)
@@ -150,13 +164,10 @@ def cpu_baseline(wname, w):
         return op.projector_forward(psd, h)
 
     run(wave[:1])  # warm-up
-    reps = 2
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        run(wave)
-    dt = (time.perf_counter() - t0) / reps
+    dt = timed(lambda: run(wave))
     return dict(value=n * 30.0 / dt, unit="audio-sec/sec", cores=cores, kind="port",
-                sample=f"{n} x 30 s clips x {reps} reps, oracle log-mel + fp32 encoder + projector (torch CPU, {cores} threads)")
+                sample=f"{n} x 30 s clips, 1 warm-up + median of 3, oracle log-mel + fp32 encoder + projector "
+                       f"(torch CPU, {cores} threads)")
 
 
 def pmc_traffic(workload, batch, kernel):
@@ -171,10 +182,58 @@ def pmc_traffic(workload, batch, kernel):
         return None
     if t.get("workload") != workload or t.get("clips_per_gpu") != batch:
         return None
-    fam = {"gemm_bf16_kernel": "gemm", "attention_kernel": "attention", "layernorm_kernel": "layernorm",
-           "logmel_tile_kernel+logmel_finish_kernel": "logmel"}.get(kernel)
-    k = t.get("kernels", {}).get(fam)
+    k = t.get("kernels", {}).get(kernel.split("+")[0])
     return k["bytes_per_launch"] if k else None
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh processes of this script, one per GPU,
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, BEFORE this process has made any GPU call (it
+    never makes one: a process that has initialised the GPU must not be replaced or forked).  Rank 0's stdout -- the one
+    JSON line -- is relayed; the exit code is non-zero if any rank fails."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read()  # EOF when rank 0 exits
+    rcs = [None] * n
+    deadline = time.time() + 600
+    while any(rc is None for rc in rcs) and time.time() < deadline:
+        for i, p_ in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p_.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            break  # one rank failed: the others would wait at a barrier for ever
+        time.sleep(0.05)
+    for i, p_ in enumerate(procs):  # stop exactly the children started above that are still running
+        if rcs[i] is None:
+            p_.kill()
+            rcs[i] = p_.wait()
+    for line in out0.decode(errors="replace").splitlines():
+        # the one JSON line goes to stdout; whatever else a library printed there (gloo / libdrm notices) to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# rocprof symbol of each profiling category of the library (include/asrk.h, asrk_profile_read)
+PROF_SYMBOLS = {0: "gemm256p_kernel", 5: "gemm256_kernel", 6: "gemm_bf16_kernel", 1: "attention_kernel",
+                2: "logmel_kernel", 3: "layernorm_kernel", 4: "splice_fwd_kernel"}
+PROF_FLOPS = (0, 5, 6, 1)
 
 
 def main():
@@ -192,31 +251,42 @@ def main():
                          "on a side stream, pad + mask on the GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = args.workload != "stub"
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+        world = dist.get_world_size()  # what is reported is what actually runs
+    elif on_gpu:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    device = torch.device("cuda", torch.cuda.current_device())
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but {world} rank(s) are running", file=sys.stderr)
+    device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
 
-    from asr_amd import LogMelFeatureExtractor, _lib
-
-    lib = _lib.load()
     w = dict(WORKLOADS[args.workload])
     if args.batch:
         w["batch"] = args.batch
     B = w["batch"]
-    fe = LogMelFeatureExtractor(feature_size=w.get("n_mels", 80))
-    wave = synth_audio(B, rank, device)
+    lib = _lib = None
+    comm_ms = []  # train-large, N > 1: host-observed time of each gradient all-reduce (enqueue -> complete)
+    if on_gpu:
+        from asr_amd import LogMelFeatureExtractor, _lib
+
+        lib = _lib.load()
+        fe = LogMelFeatureExtractor(feature_size=w.get("n_mels", 80))
+        wave = synth_audio(B, rank, device)
     prefetch_iter = None
     if args.host_input in ("prefetch", "prefetch16"):
         from asr_amd.collate import FeaturePrefetcher, pack_ragged
@@ -250,7 +320,13 @@ def main():
         if prefetch_iter is not None:
             return next(prefetch_iter).input_features
         return fe.extract_from_device(fetch())
-    if args.workload == "splice":
+    if args.workload == "stub":
+        gcpu = torch.Generator().manual_seed(rank)
+        a_ = torch.randn((B, 256, 256), generator=gcpu)
+
+        def step():
+            return torch.bmm(a_, a_)
+    elif args.workload == "splice":
         from asr_amd.splice import splice_audio_embeddings
 
         g = torch.Generator(device=device).manual_seed(rank)
@@ -273,6 +349,8 @@ def main():
         reducer = FlatGradAllReducer(proj.parameters()) if dist is not None else None
         # the decoder is outside this path: its gradient w.r.t. the audio embeddings is a fixed synthetic tensor
         g_up = (torch.randn((B, 1500, w["text_dim"]), device=device) * 1e-2).to(torch.bfloat16)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        timing = {"on": False}
 
         def step():
             feats = features()
@@ -284,7 +362,13 @@ def main():
                     p_.grad = None
             emb.backward(g_up)
             if reducer is not None:
+                if timing["on"]:
+                    ev[0].record()
                 reducer.all_reduce()
+                if timing["on"]:
+                    ev[1].record()
+                    ev[1].synchronize()
+                    comm_ms.append(ev[0].elapsed_time(ev[1]))
             return emb.detach()
     else:
         enc, proj = seeded_models(w, device)
@@ -295,10 +379,12 @@ def main():
                 return proj(enc(feats))
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         out = step()
@@ -307,66 +393,85 @@ def main():
     for _ in range(args.steps):
         out = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_rank = time.perf_counter() - t0
+    dt, rank_ms = dt_rank, [dt_rank / args.steps * 1e3]
     if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor([dt_rank], device=device, dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        rank_ms = [float(t_.item()) / args.steps * 1e3 for t_ in gathered]
+        dt = max(rank_ms) * args.steps / 1e3  # the slowest rank's time
     assert torch.isfinite(out.float()).all()
 
-    # ---- instrumented pass (rank 0): HIP events around every launch of the hot kernels
+    # ---- instrumented pass (rank 0): HIP events around every launch of the hot kernels, on their launch stream
     roofline = None
     stages = {}
-    if rank == 0:
+    if rank == 0 and on_gpu:
+        n_inst = min(args.steps, 3)
         lib.asrk_profile_enable(1)
-        for _ in range(min(args.steps, 3)):
+        for _ in range(n_inst):
             step()
         torch.cuda.synchronize()
         lib.asrk_profile_enable(0)
-        names = {_lib.PROF_GEMM: "gemm_bf16_kernel", _lib.PROF_ATTENTION: "attention_kernel",
-                 _lib.PROF_LOGMEL: "logmel_tile_kernel+logmel_finish_kernel", _lib.PROF_NORM: "layernorm_kernel",
-                 _lib.PROF_SPLICE: "splice_fwd_kernel"}
         tot = {}
-        for cat, nm in names.items():
+        fam = {}
+        for cat, nm in PROF_SYMBOLS.items():
             ms, work, n = _lib.profile_read(cat)
             if n:
                 tot[cat] = (ms, work, n)
-                is_flops = cat in (_lib.PROF_GEMM, _lib.PROF_ATTENTION)
+                is_flops = cat in PROF_FLOPS
                 ach = work / (ms * 1e-3) / (1e12 if is_flops else 1e9)
-                stages[nm] = dict(ms_per_step=ms / min(args.steps, 3), launches_per_step=n // min(args.steps, 3),
+                stages[nm] = dict(ms_per_step=ms / n_inst, launches_per_step=n / n_inst, avg_launch_us=ms * 1e3 / n,
                                   achieved=ach, unit="TFLOP/s" if is_flops else "GB/s",
                                   frac=ach / (PEAK_BF16_TFLOPS if is_flops else PEAK_HBM_GBS))
-        dom = max(tot, key=lambda c: tot[c][0])
-        ms, work, n = tot[dom]
-        if dom in (_lib.PROF_GEMM, _lib.PROF_ATTENTION):
+                if nm.startswith("gemm"):
+                    f_ = fam.setdefault("gemm (all three kernels)", [0.0, 0.0, 0])
+                    f_[0] += ms
+                    f_[1] += work
+                    f_[2] += n
+        for nm, (ms, work, n) in fam.items():
             ach = work / (ms * 1e-3) / 1e12
-            roofline = dict(bound="mfma", kernel=names[dom], achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+            stages[nm] = dict(ms_per_step=ms / n_inst, launches_per_step=n / n_inst, avg_launch_us=ms * 1e3 / n,
+                              achieved=ach, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS)
+        dom = max(tot, key=lambda c: tot[c][0])  # the kernel (rocprof symbol) with the most GPU time
+        ms, work, n = tot[dom]
+        if dom in PROF_FLOPS:
+            ach = work / (ms * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel=PROF_SYMBOLS[dom], achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                             frac=ach / PEAK_BF16_TFLOPS, traffic=None, avg_launch_us=ms * 1e3 / n, launches=n)
         else:
             ach = work / (ms * 1e-3) / 1e9
-            roofline = dict(bound="hbm", kernel=names[dom], achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+            roofline = dict(bound="hbm", kernel=PROF_SYMBOLS[dom], achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=ach / PEAK_HBM_GBS, traffic=None, avg_launch_us=ms * 1e3 / n, launches=n)
-
-    if rank == 0 and roofline is not None:
         roofline["traffic"] = pmc_traffic(args.workload, B, roofline["kernel"])
+    if comm_ms is not None and w.get("train") and dist is not None:
+        # the collective's own time, outside the timed region: three more steps with events around the all-reduce
+        timing["on"] = True
+        for _ in range(3):
+            step()
+        timing["on"] = False
+        barrier()
     if rank == 0:
         value = world * B * 30.0 * args.steps / dt
         res = {
             "metric": METRIC, "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.workload == "logmel" else "bf16", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_ranks": rank_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.workload in ("logmel", "stub") else "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "clips_per_gpu": B, "clip_seconds": 30, "global_batch": world * B,
                        **{k: v for k, v in w.items() if k != "batch"},
                        "parallelism": f"dp{world} (independent clips, no data-path collective)"},
             "roofline": roofline, "stages": stages,
         }
+        if comm_ms:
+            res["grad_allreduce_ms"] = float(np.median(comm_ms))
         if args.host_input:
             res["data"] = "synthetic, copied from pinned host memory every step (diagnostic, not the contract's value)"
-        if args.workload not in ("logmel", "splice"):
+        if args.workload not in ("logmel", "splice", "stub"):
             fl = flops_per_clip(w)
             res["pipeline_tflops"] = fl * world * B * args.steps / dt / 1e12
             res["flops_per_clip"] = fl
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and on_gpu:
             torch.cuda.synchronize()
             res["cpu_baseline"] = cpu_baseline(args.workload, w)
         print(json.dumps(res), flush=True)

@@ -202,9 +202,11 @@ int asrk_attention_log2_bf16(const void* qkv, void* out, int B, int T, int H, vo
 /* ------------------------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference, which has no profiler: SURVEY section 5).
  * When enabled, every GEMM / attention / log-mel / LayerNorm launch is bracketed by HIP events on
- * its own stream; asrk_profile_read sums one category (0 GEMM: work = 2MNK flops, 1 attention:
- * 4*B*H*T*T*64 flops, 2 log-mel: algorithmic bytes, 3 LayerNorm: bytes, 4 embed splice: bytes) after the caller has
- * synchronised.  bench.py uses it for the `roofline` object.  Off by default.
+ * its own stream; asrk_profile_read sums one category -- one per rocprof symbol: 0 gemm256p_kernel (persistent
+ * 256 x 256 tiles), 5 gemm256_kernel (one 256 x 256 tile per workgroup), 6 gemm_bf16_kernel (128 x 128 tiles), all
+ * with work = 2MNK flops; 1 attention: 4*B*H*T*T*64 flops; 2 log-mel: algorithmic bytes; 3 LayerNorm: bytes;
+ * 4 embed splice: bytes -- after the caller has synchronised.  bench.py uses it for the `roofline` object.  Off by
+ * default.
  * ---------------------------------------------------------------------------------------- */
 int asrk_profile_enable(int on);
 int asrk_profile_read(int category, double* total_ms, double* total_work, int* launches, int reset);

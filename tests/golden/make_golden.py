@@ -172,8 +172,31 @@ def gen_projector():
         proj.linear_2.bias.abs().max(), proj.norm.weight.mean()))
 
 
+# ------------------------------------------------------------------------------------ preprocessor_config.json
+def gen_preprocessor():
+    """the file stock transformers writes with save_pretrained (what
+    src/modeling.py:157-161 puts next to the model), kept as a fixture so that the CPU suite can check
+    that our extractor reads a stock-written file without importing transformers."""
+    import json
+    import tempfile
+
+    import transformers
+    from transformers import WhisperFeatureExtractor
+
+    for n_mels in (80, 128):
+        with tempfile.TemporaryDirectory() as d:
+            WhisperFeatureExtractor(feature_size=n_mels, return_attention_mask=True).save_pretrained(d)
+            cfg = json.load(open(os.path.join(d, "preprocessor_config.json")))
+        cfg["_written_by"] = f"transformers {transformers.__version__} WhisperFeatureExtractor.save_pretrained"
+        with open(os.path.join(HERE, f"hf_preprocessor_config_{n_mels}.json"), "w") as f:
+            json.dump(cfg, f, indent=2, sort_keys=True)
+        print(f"hf_preprocessor_config_{n_mels}.json:", sorted(cfg))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projector"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projector", "preprocessor"]
+    if "preprocessor" in which:
+        gen_preprocessor()
     if "logmel" in which:
         gen_logmel()
     if "encoder" in which:

@@ -81,6 +81,106 @@ def test_extractor_save_load_roundtrip(tmp_path):
     assert fe2.feature_size == 128 and fe2.return_attention_mask is True
 
 
+def test_extractor_reads_a_stock_written_preprocessor_config(golden_dir, tmp_path):
+    """Row f4, ours <- stock: tests/golden/hf_preprocessor_config_*.json were written by stock transformers'
+    WhisperFeatureExtractor.save_pretrained (tests/golden/make_golden.py::gen_preprocessor); the reference puts such a
+    file next to the model (src/modeling.py:157-161)."""
+    import json
+    import shutil
+
+    from asr_amd import LogMelFeatureExtractor
+
+    for n_mels in (80, 128):
+        d = tmp_path / f"stock{n_mels}"
+        d.mkdir()
+        shutil.copy(f"{golden_dir}/hf_preprocessor_config_{n_mels}.json", d / "preprocessor_config.json")
+        stock = json.load(open(d / "preprocessor_config.json"))
+        fe = LogMelFeatureExtractor.from_pretrained(str(d))
+        for k in ("feature_size", "sampling_rate", "hop_length", "chunk_length", "n_fft", "padding_value", "dither",
+                  "return_attention_mask", "n_samples", "nb_max_frames", "padding_side"):
+            assert getattr(fe, k) == stock[k], k
+        assert fe.feature_size == n_mels and fe.mel_filters.shape == (201, n_mels)
+        # and what we write holds every key the stock file holds, with the same values
+        mine = fe.to_dict()
+        for k, v in stock.items():
+            if not k.startswith("_"):
+                assert mine[k] == v, k
+
+
+def test_stock_transformers_reads_our_preprocessor_config(tmp_path):
+    """Row f4, stock <- ours: stock WhisperFeatureExtractor.from_pretrained loads the file our save_pretrained writes,
+    with equal fields and a bit-equal filter bank.  Runs where transformers is importable (the build container)."""
+    transformers = pytest.importorskip("transformers")
+    from asr_amd import LogMelFeatureExtractor
+
+    for n_mels in (80, 128):
+        ours = LogMelFeatureExtractor(feature_size=n_mels, return_attention_mask=True)
+        d = tmp_path / f"ours{n_mels}"
+        ours.save_pretrained(str(d))
+        hf = transformers.WhisperFeatureExtractor.from_pretrained(str(d))
+        assert type(hf).__name__ == "WhisperFeatureExtractor"
+        for k in ("feature_size", "sampling_rate", "hop_length", "chunk_length", "n_fft", "padding_value", "dither",
+                  "return_attention_mask", "n_samples", "nb_max_frames", "padding_side"):
+            assert getattr(hf, k) == getattr(ours, k), k
+        assert np.array_equal(np.asarray(hf.mel_filters), ours.mel_filters)
+        # and back: what stock transformers re-saves is read by ours
+        d2 = tmp_path / f"hf{n_mels}"
+        hf.save_pretrained(str(d2))
+        again = LogMelFeatureExtractor.from_pretrained(str(d2))
+        assert again.to_dict() == ours.to_dict()
+
+
+def test_forked_child_is_refused_with_guidance():
+    """SURVEY section 8(b): the reference runs the extractor inside forked DataLoader workers (src/train.py:172-180);
+    a HIP context does not survive fork(), so the drop-in must notice and say what to do instead."""
+    from asr_amd import LogMelFeatureExtractor, _lib
+
+    _lib.load()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # child: report through the pipe, never return into pytest
+        msg = "no error"
+        try:
+            try:
+                _lib.load()
+            except _lib.AsrkError as e:
+                msg = "load: " + str(e)
+            try:
+                LogMelFeatureExtractor()(np.zeros(1600, dtype=np.float32), sampling_rate=16000)
+                msg += " | call: no error"
+            except _lib.AsrkError as e:
+                msg += " | call: " + str(e)
+            # the CPU-only host steps stay usable in a worker
+            host, lengths, _ = LogMelFeatureExtractor().prepare_host([np.ones(10, dtype=np.float32)])
+            msg += f" | host ok {tuple(host.shape)} {int(lengths[0])}"
+        finally:
+            os.write(w, msg.encode())
+            os._exit(0)
+    os.close(w)
+    out = b""
+    while True:
+        chunk = os.read(r, 65536)
+        if not chunk:
+            break
+        out += chunk
+    os.waitpid(pid, 0)
+    out = out.decode()
+    assert out.count("forked child process") == 2, out
+    assert "num_workers=0" in out and "FeaturePrefetcher" in out
+    assert "host ok (1, 480000) 10" in out
+    _lib.assert_not_forked()  # the parent itself is fine
+
+
+def test_device_cpu_is_an_explicit_error():
+    """HF's device="cpu" means CPU arithmetic; the drop-in refuses instead of silently computing on a GPU."""
+    from asr_amd import LogMelFeatureExtractor, _lib
+
+    with pytest.raises(_lib.AsrkError, match="GPU only"):
+        LogMelFeatureExtractor()(np.zeros(1600, dtype=np.float32), sampling_rate=16000, device="cpu")
+    with pytest.raises(_lib.AsrkError, match="GPU only"):
+        LogMelFeatureExtractor(device="cpu")(np.zeros(1600, dtype=np.float32), sampling_rate=16000)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
 def test_product_fails_loudly_without_a_gpu():
     """No CPU fallback anywhere: without a GPU the product raises instead of computing."""

@@ -126,13 +126,17 @@ def test_gemm_gelu_epilogue_accuracy(lib, M, out_bf16):
 
 def test_persistent_gemm_sweep():
     """The persistent kernel's tile stream over many small shapes (see tests/persistent_gemm_sweep.py), forced by the
-    measurement switches, which are read once per process: hence one child process for the whole sweep."""
+    measurement switches.  Those exist only in the diagnostic build of the same sources (asr_amd/libasrk_diag.so,
+    `make -C asr_amd/csrc diag`, built by __graft_entry__.build()): the product library reads no environment
+    variable.  The switches are read once per process, hence one child process for the whole sweep."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ASRK_GEMM_TILE="256", ASRK_GEMM_CFG="4", PYTHONPATH=root)
+    diag = os.path.join(root, "asr_amd", "libasrk_diag.so")
+    assert os.path.exists(diag), "build it: make -C asr_amd/csrc diag"
+    env = dict(os.environ, ASRK_LIB_PATH=diag, ASRK_GEMM_TILE="256", ASRK_GEMM_CFG="4", PYTHONPATH=root)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "persistent_gemm_sweep.py")], env=env, capture_output=True,
                        text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -20,7 +20,7 @@ def extractors():
 
 @pytest.mark.parametrize("n_mels", [80, 128])
 @pytest.mark.parametrize("case", list(signals.LOGMEL_CASES))
-def test_single_clip_matches_golden(extractors, golden_dir, n_mels, case):
+def test_single_clip_matches_golden(extractors, golden_dir, margins, n_mels, case):
     g = np.load(f"{golden_dir}/logmel_{n_mels}.npz")
     clip = signals.LOGMEL_CASES[case][0]()
     r = extractors[n_mels](clip, sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
@@ -29,13 +29,14 @@ def test_single_clip_matches_golden(extractors, golden_dir, n_mels, case):
     assert feats.shape == (1, n_mels, 3000)
     ref = g[case + "__features"]
     err = np.abs(feats[0] - ref).max()
+    margins.add(f"log-mel vs HF fixture, {case}/{n_mels} mel", err, TOL, "abs")
     assert err <= TOL, f"{case}/{n_mels}: max abs err {err:.3e}"
     assert r.attention_mask.dtype == torch.int32
     assert np.array_equal(r.attention_mask.cpu().numpy()[0], g[case + "__mask"])
 
 
 @pytest.mark.parametrize("n_mels", [80, 128])
-def test_collator_batch_matches_golden(extractors, golden_dir, n_mels):
+def test_collator_batch_matches_golden(extractors, golden_dir, margins, n_mels):
     g = np.load(f"{golden_dir}/logmel_{n_mels}.npz")
     names = ["short3005", "speechlike12", "tiny250", "noise30"]
     clips = [signals.LOGMEL_CASES[n][0]() for n in names]
@@ -45,30 +46,36 @@ def test_collator_batch_matches_golden(extractors, golden_dir, n_mels):
     assert feats.shape == (4, n_mels, 3000)
     assert np.array_equal(r["attention_mask"].cpu().numpy(), g["batch__mask"])
     for i, n in enumerate(names):
-        assert np.abs(feats[i] - g[n + "__features"]).max() <= TOL, n
+        err = np.abs(feats[i] - g[n + "__features"]).max()
+        margins.add(f"log-mel collator batch vs HF fixture, {n}/{n_mels} mel", err, TOL, "abs")
+        assert err <= TOL, n
     # per-clip max: a clip's features do not depend on its batch neighbours
     alone = extractors[n_mels](clips[1], sampling_rate=16000, return_tensors="np").input_features
     assert np.array_equal(alone[0], feats[1])
 
 
 @pytest.mark.parametrize("n_mels", [80, 128])
-def test_padding_longest(extractors, golden_dir, n_mels):
+def test_padding_longest(extractors, golden_dir, margins, n_mels):
     g = np.load(f"{golden_dir}/logmel_{n_mels}.npz")
     clips = [signals.LOGMEL_CASES["short3005"][0](), signals.LOGMEL_CASES["tiny250"][0]()]
     r = extractors[n_mels](clips, sampling_rate=16000, return_tensors="np", return_attention_mask=True,
                            padding="longest")
     assert r.input_features.shape == g["longest__features"].shape
-    assert np.abs(r.input_features - g["longest__features"]).max() <= TOL
+    err = np.abs(r.input_features - g["longest__features"]).max()
+    margins.add(f"log-mel padding=longest vs HF fixture, {n_mels} mel", err, TOL, "abs")
+    assert err <= TOL
     assert np.array_equal(r.attention_mask, g["longest__mask"])
 
 
-def test_matches_oracle_on_random_batch(extractors):
+def test_matches_oracle_on_random_batch(extractors, margins):
     rng = np.random.default_rng(5)
     lens = [480000, 16000, 77777, 401, 239999]
     clips = [np.clip(rng.standard_normal(n) * 0.2, -1, 1).astype(np.float32) for n in lens]
     r = extractors[80](clips, sampling_rate=16000, return_tensors="np", return_attention_mask=True)
     o = oracle_logmel.extract(clips, n_mels=80, sampling_rate=16000)
-    assert np.abs(r.input_features - o["input_features"]).max() <= TOL
+    err = np.abs(r.input_features - o["input_features"]).max()
+    margins.add("log-mel ragged batch vs oracle, 80 mel", err, TOL, "abs")
+    assert err <= TOL
     assert np.array_equal(r.attention_mask, o["attention_mask"])
 
 

@@ -1,5 +1,5 @@
 """Diagnostic: phase times of the persistent 256x256 GEMM (asrk_gemm256p.hip) from in-kernel s_memtime stamps
-(needs asr_amd/libasrk_diag.so from tools/build_diag.sh; run with ASRK_GEMM_TILE=256 ASRK_GEMM_CFG=4)."""
+(needs asr_amd/libasrk_stamps.so from tools/build_diag.sh; run with ASRK_GEMM_TILE=256 ASRK_GEMM_CFG=4)."""
 import ctypes
 import os
 import sys
@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.environ.get("ASRK_DIAG_LIB", os.path.join(ROOT, "asr_amd", "libasrk_diag.so")))
+lib = ctypes.CDLL(os.environ.get("ASRK_DIAG_LIB", os.path.join(ROOT, "asr_amd", "libasrk_stamps.so")))
 from ctypes import c_float, c_int, c_int64, c_void_p  # noqa: E402
 
 lib.asrk_gemm_bf16.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,

@@ -1,5 +1,5 @@
 """Diagnostic: per-workgroup phase times of the 256x256 GEMM from in-kernel s_memtime stamps
-(needs asr_amd/libasrk_diag.so from tools/build_diag.sh).  Not part of the product or the tests."""
+(needs asr_amd/libasrk_stamps.so from tools/build_diag.sh).  Not part of the product or the tests."""
 import ctypes
 import os
 import sys
@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "asr_amd", "libasrk_diag.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "asr_amd", "libasrk_stamps.so"))
 from ctypes import c_float, c_int, c_int64, c_void_p  # noqa: E402
 
 lib.asrk_gemm_bf16.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int,

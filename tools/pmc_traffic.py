@@ -1,4 +1,5 @@
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into HBM bytes per launch, per kernel family.
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into HBM bytes per launch, per kernel symbol
+(the names bench.py's `roofline.kernel` / `stages` use).
 
     python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [workload] [clips_per_gpu]
 
@@ -12,7 +13,11 @@ import json
 import os
 import sys
 
-FAMILIES = {"gemm": "gemm", "attention_kernel": "attention", "layernorm_kernel": "layernorm", "logmel": "logmel"}
+# substring of the rocprof kernel name -> key.  The log-mel front-end is one logical launch: its bytes are summed over
+# all its kernels and divided by the launches of the tile kernel alone (COUNT_ONLY).
+FAMILIES = {"gemm256p_kernel": "gemm256p_kernel", "gemm256_kernel": "gemm256_kernel", "gemm_bf16_kernel": "gemm_bf16_kernel",
+            "attention_kernel": "attention_kernel", "layernorm_kernel": "layernorm_kernel", "logmel": "logmel_kernel"}
+NOT_A_LAUNCH = ("logmel_finish_kernel",)
 
 
 def family(name):
@@ -34,7 +39,8 @@ def collect(d, counter):
                 if fam is None:
                     continue
                 tot[fam] = tot.get(fam, 0.0) + float(row["Counter_Value"])
-                cnt[fam] = cnt.get(fam, 0) + 1
+                if not any(k in row["Kernel_Name"] for k in NOT_A_LAUNCH):
+                    cnt[fam] = cnt.get(fam, 0) + 1
     return tot, cnt
 
 
