@@ -144,10 +144,17 @@ static_assert((size_t)NGROUPS * YGROUP * 8 <= (size_t)NGROUPS * 20 * EROW * 8 + 
 
 }  // namespace
 
+// Scratch of asrk_logmel_f32_noalloc: the per-clip maxima (ordered-integer keys), one word per clip.  In host code this
+// name is only a stand-in for the symbol, not a device address: every device has its own copy at its own address, which
+// asrk_logmel_plan_create looks up once (hipGetSymbolAddress, with the plan's device current) and keeps in the plan;
+// kernels and hipMemsetAsync only ever get that pointer.
+static __device__ __align__(256) unsigned g_noalloc_clip_max[ASRK_LOGMEL_NOALLOC_MAX_CLIPS];
+
 struct asrk_logmel_plan {
     int n_mels;
     int device;
-    MelTables* tables;  // device
+    MelTables* tables;          // device
+    unsigned* noalloc_scratch;  // this device's address of g_noalloc_clip_max
 };
 
 extern "C" int asrk_logmel_plan_create(int n_mels, const float* mel_filters, asrk_logmel_plan** plan) {
@@ -183,6 +190,17 @@ extern "C" int asrk_logmel_plan_create(int n_mels, const float* mel_filters, asr
         return ASRK_ERR_HIP;
     }
     delete h;
+    // one-time set-up for the entry point that allocates nothing: this device's address of the static scratch array, and
+    // the tile kernel's LDS opt-in (so that the first asrk_logmel_f32_noalloc call changes no function attribute either)
+    void* sym = nullptr;
+    static std::atomic<uint64_t> lds_set{0};
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_noalloc_clip_max)) != hipSuccess || !sym ||
+        asrk_max_lds_once((const void*)logmel_tile_kernel, (int)TILE_LDS_BYTES, lds_set) != ASRK_OK) {
+        (void)hipFree(p->tables);
+        delete p;
+        return ASRK_ERR_HIP;
+    }
+    p->noalloc_scratch = static_cast<unsigned*>(sym);
     *plan = p;
     return ASRK_OK;
 }
@@ -193,35 +211,63 @@ extern "C" void asrk_logmel_plan_destroy(asrk_logmel_plan* plan) {
     delete plan;
 }
 
-extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out,
-                               float* clip_max_ws, void* stream) {
-    if (!plan || !wave || !out || !clip_max_ws) return ASRK_ERR_NULL;
-    if (B < 0 || n_samples <= NFFT / 2) return ASRK_ERR_SHAPE;
-    if (((uintptr_t)out & 15) || ((uintptr_t)wave & 3)) return ASRK_ERR_ALIGN;
-    if (B == 0) return ASRK_OK;
+namespace {
+// Both entry points: clear the per-clip maxima, tile kernel, finish kernel.  `prof`: bracket with events when the
+// measurement hook is on (event creation allocates, so the no-alloc entry point never does).
+int logmel_launch(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out, unsigned* clip_max_key,
+                  bool prof_ok, hipStream_t st) {
     const int n_frames = n_samples / HOP;
-    if (n_frames < 1 || B > 65535) return ASRK_ERR_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
     static std::atomic<uint64_t> lds_set{0};
     if (asrk_max_lds_once((const void*)logmel_tile_kernel, (int)TILE_LDS_BYTES, lds_set) != ASRK_OK) return ASRK_ERR_HIP;
-    ASRK_CHECK_HIP(hipMemsetAsync(clip_max_ws, 0, (size_t)B * 4, st));
+    ASRK_CHECK_HIP(hipMemsetAsync(clip_max_key, 0, (size_t)B * 4, st));
     // algorithmic bytes: read the waveform once, write the features once
-    AsrkProfScope prof(ASRK_PROF_LOGMEL, (double)B * ((double)n_samples * 4 + (double)plan->n_mels * n_frames * 4), st);
+    AsrkProfScope prof(prof_ok ? ASRK_PROF_LOGMEL : -1, (double)B * ((double)n_samples * 4 + (double)plan->n_mels * n_frames * 4), st);
     dim3 grid((n_frames + TILE_F - 1) / TILE_F, B);
     hipLaunchKernelGGL(logmel_tile_kernel, grid, dim3(NTHREADS), TILE_LDS_BYTES, st, wave, n_samples, n_frames,
-                       plan->n_mels, plan->tables, out, reinterpret_cast<unsigned*>(clip_max_ws));
+                       plan->n_mels, plan->tables, out, clip_max_key);
     ASRK_CHECK_HIP(hipGetLastError());
     const int per_clip = plan->n_mels * n_frames;
-    const unsigned* key = reinterpret_cast<const unsigned*>(clip_max_ws);
     if ((per_clip & 3) == 0) {
         int gx = (per_clip / 4 + 255) / 256;
         gx = gx > 64 ? 64 : gx;
-        hipLaunchKernelGGL(logmel_finish_kernel<true>, dim3(gx, B), dim3(256), 0, st, out, key, per_clip);
+        hipLaunchKernelGGL(logmel_finish_kernel<true>, dim3(gx, B), dim3(256), 0, st, out, clip_max_key, per_clip);
     } else {
         int gx = (per_clip + 255) / 256;
         gx = gx > 64 ? 64 : gx;
-        hipLaunchKernelGGL(logmel_finish_kernel<false>, dim3(gx, B), dim3(256), 0, st, out, key, per_clip);
+        hipLaunchKernelGGL(logmel_finish_kernel<false>, dim3(gx, B), dim3(256), 0, st, out, clip_max_key, per_clip);
     }
     ASRK_CHECK_HIP(hipGetLastError());
     return ASRK_OK;
+}
+
+int logmel_check(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, const float* out) {
+    if (!plan || !wave || !out) return ASRK_ERR_NULL;
+    if (B < 0 || n_samples <= NFFT / 2) return ASRK_ERR_SHAPE;
+    if (((uintptr_t)out & 15) || ((uintptr_t)wave & 3)) return ASRK_ERR_ALIGN;
+    if (n_samples / HOP < 1 || B > 65535) return ASRK_ERR_SHAPE;
+    return ASRK_OK;
+}
+}  // namespace
+
+extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out,
+                               float* clip_max_ws, void* stream) {
+    if (!clip_max_ws) return ASRK_ERR_NULL;
+    const int rc = logmel_check(plan, wave, B, n_samples, out);
+    if (rc != ASRK_OK) return rc;
+    if (B == 0) return ASRK_OK;
+    return logmel_launch(plan, wave, B, n_samples, out, reinterpret_cast<unsigned*>(clip_max_ws), true, (hipStream_t)stream);
+}
+
+// The variant that allocates nothing (include/asrk.h): the per-clip maxima live in this device's copy of
+// g_noalloc_clip_max instead of a caller-provided workspace.  No hipMalloc / hipFree / event creation on this path.
+extern "C" int asrk_logmel_f32_noalloc(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out,
+                                       void* stream) {
+    const int rc = logmel_check(plan, wave, B, n_samples, out);
+    if (rc != ASRK_OK) return rc;
+    if (B > ASRK_LOGMEL_NOALLOC_MAX_CLIPS) return ASRK_ERR_WORKSPACE;  // beyond the static scratch: use asrk_logmel_f32
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return ASRK_ERR_HIP;
+    if (dev != plan->device || !plan->noalloc_scratch) return ASRK_ERR_UNSUPPORTED;  // the scratch address is per device
+    if (B == 0) return ASRK_OK;
+    return logmel_launch(plan, wave, B, n_samples, out, plan->noalloc_scratch, false, (hipStream_t)stream);
 }

@@ -15,7 +15,7 @@ struct AsrkProfScope {
     int id;
     hipStream_t st;
     AsrkProfScope(int cat, double work, hipStream_t s) : id(-1), st(s) {
-        if (asrk_prof_enabled()) id = asrk_prof_begin(cat, work, s);
+        if (cat >= 0 && asrk_prof_enabled()) id = asrk_prof_begin(cat, work, s);  // cat < 0: never profiled
     }
     ~AsrkProfScope() {
         if (id >= 0) asrk_prof_end(id, st);

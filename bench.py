@@ -19,7 +19,7 @@ Workloads (BASELINE.json configs):
   pipeline-large  16 x 30 s per GPU, large-v3 dims (d1280 L32 H20 ffn5120, 128 mel)
   train-large     configs[3]: pipeline-large plus projector backward (synthetic upstream gradient) and, for N > 1,
                   one flat RCCL all-reduce of the projector gradients per step
-  logmel          256 x 30 s per GPU, front-end only (configs[1]), HBM-bound
+  logmel          256 x 30 s per GPU, front-end only (configs[1]), HBM-bound; logmel-128: the same with 128 mel bins
   splice          SURVEY 8(f2): the embed splice of ASRModel.forward alone, 64 samples (HBM-bound copy)
   stub            no GPU: a small CPU matmul per step over gloo; exists so that the launcher, the barriers and the
                   max-over-ranks timing can be tested at world size 2 without a GPU (tests/test_bench_launcher.py)
@@ -48,6 +48,7 @@ WORKLOADS = {
     # BASELINE.json configs[3]: large-v3-class encoder forward + projector forward/backward + gradient all-reduce
     "train-large": dict(batch=16, d_model=1280, layers=32, heads=20, ffn=5120, n_mels=128, text_dim=960, train=True),
     "logmel": dict(batch=256, n_mels=80),
+    "logmel-128": dict(batch=256, n_mels=128),  # configs[1] at the large-v3 front-end width
     # the embed splice of ASRModel.forward, 64 samples x (64 text tokens + 1500 audio
     # positions) x 960 (SmolLM2-360M width), bf16 like the decoder; HBM-bound copy
     "splice": dict(batch=64, text_len=64, text_dim=960),
@@ -125,7 +126,7 @@ def cpu_baseline(wname, w):
         dt = timed(lambda: osp.splice(text, audio, ids, labels, 49153), reps=5)
         return dict(value=n * 30.0 / dt, unit="audio-sec/sec", cores=1, kind="port",
                     sample=f"{n} samples, median of 5, NumPy oracle splice (fp32, single thread)")
-    if wname == "logmel":
+    if wname.startswith("logmel"):
         n = 16
         wave = np.clip(0.1 * rng.standard_normal((n, 480000), dtype=np.float32), -1, 1)
         ol.log_mel(wave[:1], w["n_mels"])
@@ -339,7 +340,7 @@ def main():
 
         def step():
             return splice_audio_embeddings(text, audio, ids, labels, chunk_id)[0]
-    elif args.workload == "logmel":
+    elif args.workload.startswith("logmel"):
         def step():
             return features()
     elif w.get("train"):
@@ -457,7 +458,7 @@ def main():
             "metric": METRIC, "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_ranks": rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.workload in ("logmel", "stub") else "bf16", "data": "synthetic",
+            "dtype": "f32" if args.workload in ("logmel", "logmel-128", "stub") else "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "clips_per_gpu": B, "clip_seconds": 30, "global_batch": world * B,
                        **{k: v for k, v in w.items() if k != "batch"},
                        "parallelism": f"dp{world} (independent clips, no data-path collective)"},
@@ -467,7 +468,7 @@ def main():
             res["grad_allreduce_ms"] = float(np.median(comm_ms))
         if args.host_input:
             res["data"] = "synthetic, copied from pinned host memory every step (diagnostic, not the contract's value)"
-        if args.workload not in ("logmel", "splice", "stub"):
+        if args.workload not in ("logmel", "logmel-128", "splice", "stub"):
             fl = flops_per_clip(w)
             res["pipeline_tflops"] = fl * world * B * args.steps / dt / 1e12
             res["flops_per_clip"] = fl

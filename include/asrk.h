@@ -66,6 +66,19 @@ void asrk_logmel_plan_destroy(asrk_logmel_plan* plan);
 int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples,
                     float* out, float* clip_max_ws, void* stream);
 
+/* The same computation for callers that cannot allocate -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which never manages device memory itself).
+ * The per-clip maxima, which asrk_logmel_f32 keeps in the caller's `clip_max_ws`, live in a static device array of
+ * ASRK_LOGMEL_NOALLOC_MAX_CLIPS words (16 KiB, held by every GPU the library runs on until the process ends) whose
+ * per-device address asrk_logmel_plan_create looks up once.  The call itself performs no hipMalloc / hipFree / event
+ * creation and is not timed by the measurement hook.  B > ASRK_LOGMEL_NOALLOC_MAX_CLIPS returns ASRK_ERR_WORKSPACE;
+ * a plan created on another device returns ASRK_ERR_UNSUPPORTED.  All calls on one GPU share that array: calls
+ * that overlap on one GPU (two streams, two threads) race -- serialise them, or use asrk_logmel_f32 with separate
+ * workspaces.  The array is cleared at the start of every call. */
+#define ASRK_LOGMEL_NOALLOC_MAX_CLIPS 4096
+int asrk_logmel_f32_noalloc(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Audio encoder forward.
  * Replaces WhisperEncoder.forward (src/modeling.py:33-40) -> HF WhisperEncoder.forward
