@@ -1,6 +1,19 @@
-// Paired-frame 400-point FFT pieces of the log-mel kernel, written so that the same source
-// compiles for the device (asrk_logmel.hip) and for a host emulation (tests/host/fft400_host.cpp)
-// that walks the lanes in a loop to check the index algebra without a GPU.
+// Paired-frame 400-point FFT pieces of the log-mel kernel, written so that the same source compiles for the device
+// (asrk_logmel.hip) and for a host emulation (tests/host/fft400_host.cpp) that walks the lanes of one wave in a loop to
+// check the index algebra without a GPU.
+//
+// Geometry.  A wave (64 lanes) owns 6 consecutive frames = 3 frame pairs; pair g is transformed by the 20 lanes
+// 20 g .. 20 g + 19 (lanes 60..63 shadow lanes 40..43: same addresses, same values) as ONE complex 400-point FFT of
+// z = x_even_frame + i x_odd_frame, factored 400 = 20 x 20:
+//   stage 1  lane j: 20-point DFT over n1 of z[20 n1 + j] (registers), times W400^(k1 j)
+//   exchange a 20 x 20 transpose inside the pair, through a wave-private LDS image [pair][k1][j] of plain floats
+//            (real parts, then imaginary parts through the same image).  It is written with ds_write_b32 and read back
+//            by rows with ds_read_b128; the dense 80-byte rows and the 1600-byte pair stride are conflict-free for both
+//            (bank arithmetic in DESIGN.md 4.1).  A wave's LDS operations execute in order, so no barrier is involved.
+//   stage 2  lane k1: 20-point DFT over n2 -> Z[k1 + 20 k2] in register k2
+//   mirror   X_even[k] = (Z[k] + conj Z[400-k]) / 2, X_odd[k] = (Z[k] - conj Z[400-k]) / 2i: bin 400 - k lives in lane
+//            (20 - k1) % 20 of the same pair, register 19 - k2 (lane 0: its own register (20 - k2) % 20), fetched by a
+//            cross-lane ds_bpermute -- no LDS image, no barrier.
 #pragma once
 #ifdef __HIPCC__
 #define ASRK_HD __device__ __forceinline__
@@ -12,24 +25,44 @@ struct float2 { float x, y; };
 constexpr int NFFT = 400;
 constexpr int HOP = 160;
 constexpr int NBINS = 201;
-constexpr int TILE_F = 32;                          // frames per workgroup
-constexpr int NGROUPS = 16;                         // frame pairs per workgroup
-constexpr int NTHREADS = NGROUPS * 20;              // 320
-constexpr int TILE_S = (TILE_F - 1) * HOP + NFFT;   // 5360 samples
-constexpr int YROW = 21;                            // complex row stride of the 20x20 exchange (conflict-free)
-constexpr int YGROUP = 20 * YROW;                   // 420 complex per group
-constexpr int EROW = 11;                            // complex per lane in the mirror exchange
-constexpr int PSTRIDE = 201;                        // floats per frame of the power image (odd: conflict-free)
+constexpr int FPW = 6;                               // frames per wave
+constexpr int PAIRS = FPW / 2;                       // frame pairs per wave
+constexpr int NWAVES = 4;                            // waves per workgroup
+constexpr int TILE_F = FPW * NWAVES;                 // 24 frames per workgroup tile (3000 = 125 tiles)
+constexpr int NTHREADS = 64 * NWAVES;                // 256
+constexpr int WAVE_S = (FPW - 1) * HOP + NFFT;       // 1200 samples under a wave's 6 frames
+constexpr int XPAIR = 400;                           // floats per pair of the exchange image [k1][j], dense
+constexpr int PSTRIDE = 204;                         // floats per frame of the power image: bins 0..200 + 3 zeros (16-byte chunks)
+constexpr int PRIV_FLOATS = FPW * PSTRIDE;           // wave-private LDS: max(exchange image 3 * 400, power image 6 * 204)
 constexpr int MAX_MELS = 128;
-constexpr int MAX_NNZ = 512;
+constexpr int MAX_NNZ = 792;                         // chunked weights: 4 + 644 (80 mels) / 4 + 784 (128 mels) for the slaney banks
+static_assert(PRIV_FLOATS >= PAIRS * XPAIR && PRIV_FLOATS % 4 == 0, "private region");
 
+constexpr int MEL_LANES = 10;                        // lanes per frame in the mel projection (6 frames x 10 = 60 lanes)
+constexpr int MAX_CHUNKS = 24;                       // chunks per mel lane, at most (20 / 24 for the slaney banks)
+
+// The slaney bank by rows, sparse, cut into 16-byte chunks on the bin grid: filter m covers the bins lo..hi, i.e. the
+// chunks lo / 4 .. hi / 4 of 4 bins each, with zero weights outside lo..hi.  Mel lane q owns the filters q, q + 10,
+// q + 20, ... and walks ONE flat list of chunks (the same length for every q, padded with all-zero chunks), so the
+// projection is a loop with a wave-uniform trip count, two ds_read_b128 per chunk and no per-filter control flow:
+// mel_chunk[e * 10 + q] = chunk of bins | chunk of mel_w << 6 | filter << 14 | (last chunk of its filter) << 21.
+constexpr int CHUNK_LAST = 1 << 21;
 struct MelTables {      // device-resident, built once per plan
     float window[NFFT];          // periodic Hann
-    float2 twiddle[NFFT];        // W400^(n2*k1) stored at [k1*20 + n2]
-    int mel_start[MAX_MELS];     // first FFT bin of each filter
-    int mel_ptr[MAX_MELS + 1];   // CSR offsets into mel_w
-    float mel_w[MAX_NNZ];
+    float2 twiddle[NFFT];        // W400^(j*k1) stored at [k1*20 + j]
+    int mel_chunk[MAX_CHUNKS * MEL_LANES];
+    float mel_w[MAX_NNZ];        // chunk 0 stays zero: the padding chunks point there
 };
+
+// lane -> (pair, index in pair); lanes 60..63 shadow lanes 40..43
+ASRK_HD int lane_pair(int lane) { return lane < 60 ? lane / 20 : 2; }
+ASRK_HD int lane_j(int lane) { return lane < 60 ? lane % 20 : lane - 60; }
+// exchange image: element (k1, j) of pair g
+ASRK_HD int xch_index(int g, int k1, int j) { return g * XPAIR + k1 * 20 + j; }
+// mirror: the lane that holds bins congruent to -k1, and the register of bin 400 - (k1 + 20 k2) there
+ASRK_HD int mirror_lane(int g, int j) { return g * 20 + (j ? 20 - j : 0); }
+ASRK_HD constexpr int mirror_reg(int k2) { return 19 - k2; }              // lanes j > 0
+ASRK_HD constexpr int mirror_reg_lane0(int k2) { return (20 - k2) % 20; }  // lane j == 0 (its own register)
 
 // ---- 20-point complex DFT in registers: 4 x 5 Good-Thomas (input n = (5 n1 + 4 n2) % 20,
 //      output k = (5 k1 + 16 k2) % 20), forward sign e^{-i...}.
@@ -71,64 +104,30 @@ ASRK_HD void dft20(float (&re)[20], float (&im)[20]) {
     }
 }
 
-
-// ---- the four per-lane steps of the paired-frame 400-point FFT.  (g, j) = (frame pair, lane in group).
-// stage 1: z[n1] = w * (x_f0 + i x_f1) at n = 20 n1 + j; 20-pt DFT over n1; twiddle; Y[g][k1][j]
-ASRK_HD void fft400_stage1(const float* S, float2* Y, const MelTables* tab, int g, int j) {
-    float re[20], im[20];
-    const float* f0 = S + (2 * g) * HOP;
-    const float* f1 = f0 + HOP;
+// stage 1 of lane j: re / im hold the raw samples of the even / odd frame at n = 20 n1 + j on entry, the twiddled
+// column Y[k1][j] on exit.  `win` and `tw` are the tables (LDS on the device).
+ASRK_HD void fft400_stage1(float (&re)[20], float (&im)[20], const float* win, const float2* tw, int j) {
 #pragma unroll
     for (int n1 = 0; n1 < 20; ++n1) {
-        const float w = tab->window[20 * n1 + j];
-        re[n1] = w * f0[20 * n1 + j];
-        im[n1] = w * f1[20 * n1 + j];
+        const float w = win[20 * n1 + j];
+        re[n1] *= w;
+        im[n1] *= w;
     }
     dft20(re, im);
-    float2* yrow = Y + g * YGROUP + j;
 #pragma unroll
-    for (int k1 = 0; k1 < 20; ++k1) {
-        const float2 tw = tab->twiddle[k1 * 20 + j];
-        float2 v;
-        v.x = re[k1] * tw.x - im[k1] * tw.y;
-        v.y = re[k1] * tw.y + im[k1] * tw.x;
-        yrow[k1 * YROW] = v;
+    for (int k1 = 1; k1 < 20; ++k1) {  // k1 = 0: W^0 = 1
+        const float2 t = tw[k1 * 20 + j];
+        const float r = re[k1] * t.x - im[k1] * t.y;
+        im[k1] = re[k1] * t.y + im[k1] * t.x;
+        re[k1] = r;
     }
 }
-// stage 2: lane (g, k1=j): 20-pt DFT over n2 -> Z[k1 + 20 k2] in register k2
-ASRK_HD void fft400_stage2(const float2* Y, int g, int j, float (&zr)[20], float (&zi)[20]) {
-    const float2* yrow = Y + g * YGROUP + j * YROW;
-#pragma unroll
-    for (int n2 = 0; n2 < 20; ++n2) {
-        const float2 v = yrow[n2];
-        zr[n2] = v.x;
-        zi[n2] = v.y;
-    }
-    dft20(zr, zi);
-}
-// mirror exchange: publish Z[k1 + 20 k2'] for k2' = 10..19 (slots 0..9) and k2' = 0 (slot 10)
-ASRK_HD void fft400_publish(float2* E, int g, int j, const float (&zr)[20], const float (&zi)[20]) {
-    float2* e = E + (g * 20 + j) * EROW;
-#pragma unroll
-    for (int q = 0; q < 10; ++q) { float2 v; v.x = zr[10 + q]; v.y = zi[10 + q]; e[q] = v; }
-    float2 v0; v0.x = zr[0]; v0.y = zi[0];
-    e[10] = v0;
-}
-// separate the two real spectra and write |X|^2 for bins 0..200 of frames 2g and 2g+1
-ASRK_HD void fft400_power(const float2* E, float* P, int g, int j, const float (&zr)[20], const float (&zi)[20]) {
-    const int jp = (20 - j) % 20;  // lane holding bins congruent to -k1
-    const float2* e = E + (g * 20 + jp) * EROW;
-    float* p0 = P + (2 * g) * PSTRIDE + j;
-    float* p1 = p0 + PSTRIDE;
-#pragma unroll
-    for (int k2 = 0; k2 <= 10; ++k2) {
-        if (k2 < 10 || j == 0) {
-            // partner bin 400 - k: slot 9 - k2 (k1 > 0) or 10 - k2 (k1 == 0; slot 10 = Z[0], slot 0 = Z[200])
-            const float2 c = e[(j == 0) ? (10 - k2) : (9 - k2)];
-            const float ar = zr[k2] + c.x, ai = zi[k2] - c.y;  // 2 * X1[k]
-            const float br = zr[k2] - c.x, bi = zi[k2] + c.y;  // 2i * X2[k]
-            p0[20 * k2] = 0.25f * (ar * ar + ai * ai);
-            p1[20 * k2] = 0.25f * (br * br + bi * bi);
-        }
-    }
+
+// power of bins k = j + 20 k2 of the even frame (p0) and the odd frame (p1) from Z[k] = (zr, zi)[k2] and the mirror
+// value c = Z[400 - k]
+ASRK_HD void fft400_power(float zr, float zi, float cr, float ci, float& p0, float& p1) {
+    const float ar = zr + cr, ai = zi - ci;  // 2 * X_even[k]
+    const float br = zr - cr, bi = zi + ci;  // 2i * X_odd[k]
+    p0 = 0.25f * (ar * ar + ai * ai);
+    p1 = 0.25f * (br * br + bi * bi);
 }

@@ -6,20 +6,45 @@
 //   hann(400) * frame -> 400-pt real DFT (hop 160, center + reflect) -> |.|^2 -> drop last frame
 //   -> mel (201 x n_mels, slaney) -> clamp 1e-10 -> log10 -> per-clip max-8 floor -> (x+4)/4.
 //
-// Kernel 1 (logmel_tile_kernel): one workgroup = 320 threads = 16 groups of 20 lanes, one tile of
-//   32 frames of one clip.  The tile's 5360 samples are read from HBM once (coalesced) into LDS.
-//   Each 20-lane group transforms TWO real frames at once as one 400-point complex FFT
-//   (z = x_even_frame + i * x_odd_frame), factored 400 = 20 x 20: every lane runs a 20-point DFT
-//   entirely in registers (4 x 5 prime-factor, no internal twiddles), the groups exchange through
-//   LDS once, and the two spectra are separated with X1[k] = (Z[k] + conj Z[400-k]) / 2,
-//   X2[k] = (Z[k] - conj Z[400-k]) / 2i.  Power spectra go to LDS, the mel projection uses the
-//   sparse rows of the filter bank (each FFT bin feeds <= 2 filters), and log10 values are written
-//   as [clip][mel][frame] with frames on the lanes (coalesced).  The per-clip maximum is reduced
-//   per workgroup and merged with one ordered-integer atomicMax.
+// Kernel 1 (logmel_tile_kernel): persistent workgroups of 4 waves (4 per CU) walk the 24-frame tiles of the batch.  A
+//   WAVE is the unit of work: it owns 6 consecutive frames = 3 frame pairs, each pair transformed by 20 lanes as one
+//   complex 400-point FFT, 400 = 20 x 20 (asrk_fft400.h): a 20-point DFT per lane in registers (4 x 5 prime-factor, no
+//   inner twiddles), a 20 x 20 transpose through a wave-private 4.8 KiB LDS image (ds_write_b32 in, ds_read_b128 out,
+//   both conflict-free; a wave's LDS operations execute in order, so there is NO workgroup barrier anywhere in the
+//   transform), a second 20-point DFT, and the separation of the two real spectra with the mirror bin fetched by a
+//   cross-lane ds_bpermute.  Samples come straight from global memory (each 20-lane group reads 80 contiguous bytes per
+//   instruction; the 60 % frame overlap is served by the vector cache), the window / twiddle / mel tables from LDS,
+//   loaded once per workgroup.  The power spectra of the wave's 6 frames go to the same private image, [frame][204];
+//   the mel projection reads them back by 16-byte chunks: lane = (frame, filters q, q + 10, ...) walks one flat,
+//   wave-uniform list of (4 bins x 4 weights) chunks of the sparse slaney bank, takes log10 at the end of each filter
+//   and puts the value into the tile's [n_mels][24] staging image.  The four waves meet only around that image (two
+//   barriers per tile).  The store pass (whole 96-byte row segments, per-wave maximum merged with one ordered-integer
+//   atomicMax) runs one tile late, behind the next tile's sample loads.
+//   36-41 KiB of LDS per workgroup and 82 VGPRs: 16 independent waves per CU, against 10 waves behind 5 barriers per
+//   tile in round 1's kernel (counter evidence: profiles/r2_logmel_*, history in DESIGN.md 4.1).
 // Kernel 2 (logmel_finish_kernel): applies max(x, clip_max - 8) and (x + 4) / 4 in place.
 #include "asrk_common.h"
 #include "asrk_fft400.h"
 #include "asrk_prof.h"
+
+#ifdef ASRK_STAMPS
+// Diagnostic build only (tools/build_diag.sh): cycles per phase of the tile kernel, summed over a workgroup's tiles by
+// wave 0 (s_memtime with a full wait in front, so a phase is charged with the latencies it exposes).
+__device__ unsigned long long g_lm_stamps[1024 * 16];
+extern "C" int asrk_debug_read_lmstamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lm_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define LSTAMP(i)                                                                              \
+    do {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+        lm_acc[i] += t_now - lm_prev;                                                          \
+        lm_prev = t_now;                                                                       \
+    } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -31,87 +56,275 @@ __device__ __forceinline__ float ordered_value(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-__global__ __launch_bounds__(NTHREADS) void logmel_tile_kernel(const float* __restrict__ wave, int n_samples,
-                                                                int n_frames, int n_mels,
-                                                                const MelTables* __restrict__ tab,
-                                                                float* __restrict__ out,
-                                                                unsigned* __restrict__ clip_max_key) {
+// Orders this wave's LDS stores before its following LDS loads of other lanes' data (the hardware runs a wave's LDS
+// operations in order; this only stops the compiler from moving them and makes it wait for the stores' data).
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+// LDS carve-up (bytes): tables | staging [n_mels][24] | 4 wave-private images
+constexpr int OFF_WIN = 0;                                   // float[400]
+constexpr int OFF_TW = OFF_WIN + NFFT * 4;                   // float2[400]
+constexpr int OFF_MI = OFF_TW + NFFT * 8;                    // int[MAX_CHUNKS][MEL_LANES]
+constexpr int OFF_MW = OFF_MI + MAX_CHUNKS * MEL_LANES * 4;  // float[MAX_NNZ]
+constexpr int OFF_STAGE = OFF_MW + MAX_NNZ * 4;              // float[n_mels][TILE_F]
+static_assert(OFF_TW % 8 == 0 && OFF_STAGE % 16 == 0, "LDS alignment");
+constexpr size_t tile_lds_bytes(int n_mels) {
+    return (size_t)OFF_STAGE + (size_t)n_mels * TILE_F * 4 + (size_t)NWAVES * PRIV_FLOATS * 4;
+}
+static_assert(tile_lds_bytes(MAX_MELS) <= 163840 / 4, "four workgroups per CU");
+
+constexpr int LOGMEL_WPS = 4;  // workgroups per CU (= waves per SIMD)
+// ROW_ITERS = ceil(n_mels / 42): the store pass is unrolled by it, so that the number of global stores per tile is known
+// at compile time.  A wave's vector-memory operations complete in issue order and the next tile's sample loads are
+// issued BEFORE this tile's stores; with a countable number of stores the compiler waits for those loads with
+// vmcnt(stores + 1) instead of vmcnt(0) -- which made every wave sit out its own stores' write latency once per tile
+// (0.14 of 0.49 ms per 256 clips).
+template <int ROW_ITERS, bool VEC>
+__global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const float* __restrict__ wave, int n_samples, int n_frames,
+                                                                   int n_mels, int tiles_per_clip, int n_tiles,
+                                                                   const MelTables* __restrict__ tab, float* __restrict__ out,
+                                                                   unsigned* __restrict__ clip_max_key, int n_chunks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* S = reinterpret_cast<float*>(smem);                                  // [TILE_S]
-    float2* Y = reinterpret_cast<float2*>(smem + TILE_S * 4);                   // [NGROUPS][YGROUP]
-    float2* E = Y;                                                              // [NGROUPS][20][EROW] (aliases Y)
-    float* P = reinterpret_cast<float*>(smem + TILE_S * 4 + NGROUPS * 20 * EROW * 8);  // [TILE_F][PSTRIDE]
-    // CSR mel rows after the P image
-    char* csr = smem + TILE_S * 4 + NGROUPS * 20 * EROW * 8 + TILE_F * PSTRIDE * 4;
-    int* Lstart = reinterpret_cast<int*>(csr);
-    int* Lptr = Lstart + MAX_MELS;
-    float* Lw = reinterpret_cast<float*>(Lptr + MAX_MELS + 1);
-    float* Lred = Lw + MAX_NNZ;  // [8] block reduction
+    float* Lwin = reinterpret_cast<float*>(smem + OFF_WIN);
+    float2* Ltw = reinterpret_cast<float2*>(smem + OFF_TW);
+    int* Lmi = reinterpret_cast<int*>(smem + OFF_MI);
+    float* Lmw = reinterpret_cast<float*>(smem + OFF_MW);
+    float* stage = reinterpret_cast<float*>(smem + OFF_STAGE);
 
     const int tid = threadIdx.x;
-    const int clip = blockIdx.y;
-    const int t0 = blockIdx.x * TILE_F;  // first frame of the tile
-    const int g = tid / 20, j = tid % 20;
-    const float* x = wave + (size_t)clip * n_samples;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* priv = stage + n_mels * TILE_F + wv * PRIV_FLOATS;
 
-    // ---- stage the tile's samples (center=True, reflect padding; torch.stft semantics)
-    const int s0 = t0 * HOP - NFFT / 2;
-    // interior tiles (no reflection, 16-byte aligned: t0 is a multiple of 32, so s0 is a multiple of 4 samples)
-    // copy with 16-byte loads; only a clip's first and last tiles take the indexed path
-    const bool interior = s0 >= 0 && s0 + TILE_S <= n_samples && ((n_samples & 3) == 0) && ((reinterpret_cast<uintptr_t>(wave) & 15) == 0);
-    if (interior) {
-        const float4* src = reinterpret_cast<const float4*>(x + s0);
-        for (int i = tid; i < TILE_S / 4; i += NTHREADS) reinterpret_cast<float4*>(S)[i] = src[i];
-    } else
-    for (int i = tid; i < TILE_S; i += NTHREADS) {
-        int s = s0 + i;
-        if (s < 0) s = -s;
-        if (s >= n_samples) s = 2 * (n_samples - 1) - s;
-        s = min(max(s, 0), n_samples - 1);  // frames past the clip end are computed but never stored
-        S[i] = x[s];
-    }
-    for (int i = tid; i < n_mels; i += NTHREADS) { Lstart[i] = tab->mel_start[i]; Lptr[i] = tab->mel_ptr[i]; }
-    if (tid == 0) Lptr[n_mels] = tab->mel_ptr[n_mels];
-    const int nnz = tab->mel_ptr[n_mels];
-    for (int i = tid; i < nnz; i += NTHREADS) Lw[i] = tab->mel_w[i];
+    // ---- tables, once per workgroup
+    for (int i = tid; i < NFFT; i += NTHREADS) { Lwin[i] = tab->window[i]; Ltw[i] = tab->twiddle[i]; }
+    for (int i = tid; i < MAX_CHUNKS * MEL_LANES; i += NTHREADS) Lmi[i] = tab->mel_chunk[i];
+    for (int i = tid; i < MAX_NNZ; i += NTHREADS) Lmw[i] = tab->mel_w[i];
     __syncthreads();
 
-    fft400_stage1(S, Y, tab, g, j);
-    __syncthreads();
-    float zr[20], zi[20];
-    fft400_stage2(Y, g, j, zr, zi);
-    __syncthreads();  // everyone is done reading Y before E (aliasing Y) is written
-    fft400_publish(E, g, j, zr, zi);
-    __syncthreads();
-    fft400_power(E, P, g, j, zr, zi);
-    __syncthreads();
+    const int g = lane_pair(lane), j = lane_j(lane);
+    const int mir = mirror_lane(g, j) * 4;  // ds_bpermute byte address of the mirror lane
+    const int mf = lane / MEL_LANES, mq = lane % MEL_LANES;  // mel projection: frame in the wave (6 = idle lanes), mel mod 10
+    const bool mel_lane = lane < FPW * MEL_LANES;
 
-    // ---- mel projection (sparse rows) + log10, frames on the lanes
-    const int f = tid & 31;
-    const bool valid = (t0 + f) < n_frames;
-    float vmax = -INFINITY;
-    float* obase = out + (size_t)clip * n_mels * n_frames + t0 + f;
-    const float* prow = P + f * PSTRIDE;
-    for (int m = tid >> 5; m < n_mels; m += NTHREADS / 32) {
-        const int b0 = Lstart[m], p0 = Lptr[m], p1 = Lptr[m + 1];
-        float acc = 0.f;
-        for (int q = p0; q < p1; ++q) acc = fmaf(Lw[q], prow[b0 + q - p0], acc);
-        // clamp(min=1e-10).log10(): silence is exactly -10.  v_log_f32 (log2, 1 ulp) * log10(2): |err| < 2e-6 here,
-        // against ~25 instructions for log10f()
-        const float v = acc > 1e-10f ? __builtin_amdgcn_logf(acc) * 0.30102999566398120f : -10.0f;
-        if (valid) {
-            obase[(size_t)m * n_frames] = v;
-            vmax = fmaxf(vmax, v);
-        }
-    }
-    vmax = wave_max(vmax);
-    if ((tid & 63) == 0) Lred[tid >> 6] = vmax;
-    __syncthreads();
-    if (tid == 0) {
-        float v = Lred[0];
+#ifdef ASRK_STAMPS
+    unsigned long long lm_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long lm_prev = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    // Work item -> (clip, tile of the clip).  Items are dealt so that concurrently running workgroups (consecutive items)
+    // cover MANY clips, four neighbouring tiles of each: with a clip's 125 tiles on 125 neighbouring workgroups, the 500
+    // waves of a clip all merged their maximum into ONE word at the same time, and an atomic on a contended word
+    // completes at ~90 per microsecond -- behind which, in issue order, the wave's next loads waited (0.14 of 0.49 ms).
+    // Four neighbours still share their overlapping samples and complete each other's 128-byte output lines in L2.
+    constexpr int TGROUP = 4;
+    const int n_clips = n_tiles / (TGROUP * ((tiles_per_clip + TGROUP - 1) / TGROUP));
+    auto item_clip = [&](int item) { return (item % (TGROUP * n_clips)) / TGROUP; };
+    auto item_tile = [&](int item) { return (item / (TGROUP * n_clips)) * TGROUP + item % TGROUP; };  // may be >= tiles_per_clip
+
+    // samples of the lane's frame pair of one tile (center=True, reflect padding; torch.stft semantics): n = 20 n1 + j
+    auto load_samples = [&](int tile, float (&re)[20], float (&im)[20]) {
+        const int clip = item_clip(tile);
+        const int tw0 = item_tile(tile) * TILE_F + FPW * wv;  // first frame of this wave
+        const float* x = wave + (size_t)clip * n_samples;
+        const int sa = (tw0 + 2 * g) * HOP - NFFT / 2 + j;  // sample of (even frame, n1 = 0)
+        const int wlo = tw0 * HOP - NFFT / 2, whi = wlo + WAVE_S - 1;
+        if (wlo >= 0 && whi < n_samples) {  // wave-uniform: no reflection anywhere under this wave
+            const float* pa = x + sa;
 #pragma unroll
-        for (int i = 1; i < NTHREADS / 64; ++i) v = fmaxf(v, Lred[i]);
-        if (v > -INFINITY) atomicMax(clip_max_key + clip, ordered_key(v));
+            for (int n1 = 0; n1 < 20; ++n1) {
+                re[n1] = pa[20 * n1];
+                im[n1] = pa[HOP + 20 * n1];
+            }
+        } else {
+            auto at = [&](int s) {
+                if (s < 0) s = -s;
+                if (s >= n_samples) s = 2 * (n_samples - 1) - s;
+                s = min(max(s, 0), n_samples - 1);  // frames past the clip end are computed but never stored
+                return x[s];
+            };
+#pragma unroll
+            for (int n1 = 0; n1 < 20; ++n1) {
+                re[n1] = at(sa + 20 * n1);
+                im[n1] = at(sa + HOP + 20 * n1);
+            }
+        }
+    };
+
+    // The store pass of a tile: its [n_mels][24] values from the staging image as whole 96-byte row segments (a per-element
+    // path when rows are not 16-byte aligned), and the per-clip maximum.  It is branch-free on purpose -- buffer stores with
+    // the out-of-range lanes pointed past the end of the clip's buffer, which the hardware drops -- so that every wave
+    // issues exactly ROW_ITERS (x 4) stores + 1 atomic per tile and the compiler can COUNT them: it runs at the top of the
+    // NEXT tile, right behind that tile's sample loads, and the wait for those loads is then vmcnt(stores + 1), not
+    // vmcnt(0).  A wave's vector-memory operations complete in issue order; with the store pass at the end of its own tile
+    // every wave sat out the write latency of its stores once per tile in front of its next loads (0.14 of 0.49 ms).
+    auto store_tile = [&](int tile_or_none) {
+        // tile_or_none < 0 (a workgroup's first pass): the same instructions with every lane out of range, so that the
+        // loop body has ONE instruction stream -- a branch around the stores would bring back the uncountable case
+        const bool valid = tile_or_none >= 0;
+        const int tile = valid ? tile_or_none : 0;
+        const int clip = __builtin_amdgcn_readfirstlane(item_clip(tile));
+        const int t0 = item_tile(tile) * TILE_F;
+        const int per_clip = n_mels * n_frames;  // < 2^29 elements (host check)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(out + (size_t)clip * per_clip))), 0, per_clip * 4, 0x00020000);
+        const int c4 = tid % 6, r0 = tid / 6;
+        const int fr = t0 + 4 * c4;
+        float vmax = -INFINITY;
+#pragma unroll
+        for (int it = 0; it < ROW_ITERS; ++it) {
+            const int r = r0 + 42 * it;
+            const bool row_ok = valid && tid < 42 * 6 && r < n_mels;
+            const float4 v = *reinterpret_cast<const float4*>(stage + (row_ok ? r : 0) * TILE_F + 4 * c4);
+            const int off = (r * n_frames + fr) * 4;
+            if (VEC) {  // n_frames % 4 == 0: a float4 is valid or invalid as a whole
+                const bool ok = row_ok && fr < n_frames;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ok ? off : 0x7fffffff, 0, 0);
+                const float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+                vmax = ok ? fmaxf(vmax, m4) : vmax;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool ok = row_ok && fr + k < n_frames;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[k]), rs, ok ? off + 4 * k : 0x7fffffff, 0, 0);
+                    vmax = ok ? fmaxf(vmax, e[k]) : vmax;
+                }
+            }
+        }
+        vmax = wave_max(vmax);
+        // unconditional (countable): a wave without a valid value contributes the key of -inf, below every real one
+        if (lane == 0) atomicMax(clip_max_key + clip, ordered_key(vmax));
+    };
+
+    float re[20], im[20];
+    int prev_tile = -1;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (item_tile(tile) >= tiles_per_clip) continue;  // padding item of the last group of four (the whole workgroup skips)
+        LSTAMP(9);  // loop overhead / previous tile's tail
+        load_samples(tile, re, im);
+        store_tile(prev_tile);  // behind this tile's loads: see store_tile
+        prev_tile = tile;
+        LSTAMP(7);  // store pass (of the previous tile)
+        LSTAMP(0);  // sample loads (what is left exposed of them)
+        fft400_stage1(re, im, Lwin, Ltw, j);
+        LSTAMP(1);  // window, DFT 1, twiddle
+
+        // ---- 20 x 20 transpose inside the pair, real parts then imaginary parts through the same private image
+        float zr[20], zi[20];
+        float* xw = priv + xch_index(g, 0, j);
+        const float4* xr = reinterpret_cast<const float4*>(priv + xch_index(g, j, 0));
+#pragma unroll
+        for (int k1 = 0; k1 < 20; ++k1) xw[k1 * 20] = re[k1];
+        wave_lds_order();
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const float4 v = xr[c];
+            zr[4 * c] = v.x; zr[4 * c + 1] = v.y; zr[4 * c + 2] = v.z; zr[4 * c + 3] = v.w;
+        }
+        wave_lds_order();
+#pragma unroll
+        for (int k1 = 0; k1 < 20; ++k1) xw[k1 * 20] = im[k1];
+        wave_lds_order();
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const float4 v = xr[c];
+            zi[4 * c] = v.x; zi[4 * c + 1] = v.y; zi[4 * c + 2] = v.z; zi[4 * c + 3] = v.w;
+        }
+        LSTAMP(2);  // exchange
+        dft20(zr, zi);  // Z[j + 20 k2] in register k2
+        LSTAMP(3);  // DFT 2
+
+        // ---- separate the two real spectra; |X|^2 of bins 0..200 into the private image [frame][bin]
+        {
+            float* p0 = priv + (2 * g) * PSTRIDE + j;
+            float* p1 = p0 + PSTRIDE;
+#pragma unroll
+            for (int k2 = 0; k2 < 10; ++k2) {
+                float cr = lane_fetch(mir, zr[mirror_reg(k2)]), ci = lane_fetch(mir, zi[mirror_reg(k2)]);
+                if (j == 0) { cr = zr[mirror_reg_lane0(k2)]; ci = zi[mirror_reg_lane0(k2)]; }
+                float a, b;
+                fft400_power(zr[k2], zi[k2], cr, ci, a, b);
+                p0[20 * k2] = a;
+                p1[20 * k2] = b;
+            }
+            if (j == 0) {  // bin 200: its mirror is itself
+                float a, b;
+                fft400_power(zr[10], zi[10], zr[mirror_reg_lane0(10)], zi[mirror_reg_lane0(10)], a, b);
+                p0[200] = a;
+                p1[200] = b;
+            } else if (j < 4) {  // bins 201..203 of the last 16-byte chunk: zeros (the exchange image leaves numbers there)
+                p0[200] = 0.f;
+                p1[200] = 0.f;
+            }
+        }
+        LSTAMP(4);  // mirror + power
+        __syncthreads();  // every wave has stored the previous tile: the staging image is free (and orders the P image)
+        LSTAMP(8);  // barrier: staging free
+
+        // ---- mel projection + log10: lane = (frame mf of the wave, filters mq, mq + 10, ...), one flat list of 16-byte
+        //      chunks (4 bins x 4 weights) per lane.  Four chunks at a time, all their loads first, so that one LDS round
+        //      trip serves 16 products (per-filter loops ran one dependent round trip per chunk: 17 k cycles per tile).
+        if (mel_lane) {
+            const char* prow = reinterpret_cast<const char*>(priv + mf * PSTRIDE);
+            const char* wbase = reinterpret_cast<const char*>(Lmw);
+            char* srow = reinterpret_cast<char*>(stage + FPW * wv + mf);
+            const int* dq = Lmi + mq;
+            float acc = 0.f;
+            for (int e0 = 0; e0 < n_chunks; e0 += 4) {  // n_chunks: a multiple of 4, the same for every lane
+                int d[4];
+                float4 w[4], q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = dq[(e0 + u) * MEL_LANES];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    q[u] = *reinterpret_cast<const float4*>(prow + ((d[u] & 63) << 4));
+                    w[u] = *reinterpret_cast<const float4*>(wbase + (((d[u] >> 6) & 255) << 4));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = fmaf(w[u].x, q[u].x, acc);
+                    acc = fmaf(w[u].y, q[u].y, acc);
+                    acc = fmaf(w[u].z, q[u].z, acc);
+                    acc = fmaf(w[u].w, q[u].w, acc);
+                    if (d[u] & CHUNK_LAST) {
+                        // clamp(min=1e-10).log10(): silence is exactly -10.  v_log_f32 (log2, 1 ulp) * log10(2):
+                        // |err| < 2e-6 here, against ~25 instructions for log10f()
+                        *reinterpret_cast<float*>(srow + ((d[u] >> 14) & 127) * (TILE_F * 4)) =
+                            acc > 1e-10f ? __builtin_amdgcn_logf(acc) * 0.30102999566398120f : -10.0f;
+                        acc = 0.f;
+                    }
+                }
+            }
+        }
+
+        LSTAMP(5);  // mel
+        __syncthreads();  // the staging image is complete; it is stored at the top of the next tile (store_tile)
+        LSTAMP(6);  // barrier: staging complete
+    }
+    if (prev_tile >= 0) store_tile(prev_tile);
+#ifdef ASRK_STAMPS
+    if (tid == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 10; ++i) g_lm_stamps[blockIdx.x * 16 + i] = lm_acc[i];
+#endif
+}
+
+using tile_kernel_t = void (*)(const float*, int, int, int, int, int, const MelTables*, float*, unsigned*, int);
+// vec: rows of the output are 16-byte aligned (n_frames % 4 == 0): float4 stores
+tile_kernel_t tile_kernel_for(int n_mels, bool vec) {
+    switch ((n_mels + 41) / 42) {
+        case 1: return vec ? logmel_tile_kernel<1, true> : logmel_tile_kernel<1, false>;
+        case 2: return vec ? logmel_tile_kernel<2, true> : logmel_tile_kernel<2, false>;  // 80 mel bins
+        case 3: return vec ? logmel_tile_kernel<3, true> : logmel_tile_kernel<3, false>;
+        case 4: return vec ? logmel_tile_kernel<4, true> : logmel_tile_kernel<4, false>;  // 128 mel bins
+        default: return nullptr;
     }
 }
 
@@ -137,11 +350,6 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ 
     }
 }
 
-constexpr size_t TILE_LDS_BYTES = (size_t)TILE_S * 4 + (size_t)NGROUPS * 20 * EROW * 8 + (size_t)TILE_F * PSTRIDE * 4 +
-                                  (size_t)(MAX_MELS + MAX_MELS + 1) * 4 + (size_t)MAX_NNZ * 4 + 8 * 4;
-static_assert((size_t)NGROUPS * YGROUP * 8 <= (size_t)NGROUPS * 20 * EROW * 8 + (size_t)TILE_F * PSTRIDE * 4,
-              "Y image must fit inside the E + P region it aliases");
-
 }  // namespace
 
 // Scratch of asrk_logmel_f32_noalloc: the per-clip maxima (ordered-integer keys), one word per clip.  In host code this
@@ -153,6 +361,8 @@ static __device__ __align__(256) unsigned g_noalloc_clip_max[ASRK_LOGMEL_NOALLOC
 struct asrk_logmel_plan {
     int n_mels;
     int device;
+    int n_cus;
+    int n_chunks;               // chunks of 4 products per mel lane (a multiple of 4)
     MelTables* tables;          // device
     unsigned* noalloc_scratch;  // this device's address of g_noalloc_clip_max
 };
@@ -168,22 +378,36 @@ extern "C" int asrk_logmel_plan_create(int n_mels, const float* mel_filters, asr
             const double a = -two_pi * (double)(n2 * k1) / NFFT;
             h->twiddle[k1 * 20 + n2] = make_float2((float)cos(a), (float)sin(a));
         }
-    int nnz = 0;
+    // sparse rows of the bank cut into 16-byte chunks on the bin grid, and every mel lane's flat list of chunks
+    int nw = 4;  // chunk 0 of mel_w = zeros: the target of the padding chunks
+    for (int i = 0; i < MAX_NNZ; ++i) h->mel_w[i] = 0.f;
+    int per_lane[MEL_LANES] = {0};
+    for (int i = 0; i < MAX_CHUNKS * MEL_LANES; ++i) h->mel_chunk[i] = 0;  // padding chunk: bins 0..3 x zero weights, no output
     for (int m = 0; m < n_mels; ++m) {
         int lo = NBINS, hi = -1;
         for (int k = 0; k < NBINS; ++k)
             if (mel_filters[(size_t)k * n_mels + m] != 0.0f) { lo = k < lo ? k : lo; hi = k; }
-        h->mel_ptr[m] = nnz;
-        h->mel_start[m] = hi < 0 ? 0 : lo;
-        if (hi >= 0) {
-            if (nnz + (hi - lo + 1) > MAX_NNZ) { delete h; return ASRK_ERR_SHAPE; }
-            for (int k = lo; k <= hi; ++k) h->mel_w[nnz++] = mel_filters[(size_t)k * n_mels + m];
-        }
+        if (hi < 0) { lo = 0; hi = 0; }  // an empty filter: one chunk of zero weights, so that it still emits log10(1e-10)
+        const int c0 = lo / 4, nch = hi / 4 - c0 + 1, q = m % MEL_LANES;
+        if (nw + 4 * nch > MAX_NNZ || nw / 4 + nch > 256 || per_lane[q] + nch > MAX_CHUNKS) { delete h; return ASRK_ERR_SHAPE; }
+        for (int k = lo; k <= hi; ++k) h->mel_w[nw + k - 4 * c0] = mel_filters[(size_t)k * n_mels + m];
+        for (int c = 0; c < nch; ++c)
+            h->mel_chunk[(per_lane[q] + c) * MEL_LANES + q] =
+                (c0 + c) | ((nw / 4 + c) << 6) | (m << 14) | (c == nch - 1 ? CHUNK_LAST : 0);
+        per_lane[q] += nch;
+        nw += 4 * nch;
     }
-    h->mel_ptr[n_mels] = nnz;
+    int n_chunks = 0;
+    for (int q = 0; q < MEL_LANES; ++q) n_chunks = per_lane[q] > n_chunks ? per_lane[q] : n_chunks;
+    n_chunks = (n_chunks + 3) / 4 * 4;
+    if (n_chunks > MAX_CHUNKS) { delete h; return ASRK_ERR_SHAPE; }
     asrk_logmel_plan* p = new asrk_logmel_plan();
     p->n_mels = n_mels;
-    if (hipGetDevice(&p->device) != hipSuccess || hipMalloc(&p->tables, sizeof(MelTables)) != hipSuccess ||
+    p->n_chunks = n_chunks;
+    p->n_cus = 256;
+    if (hipGetDevice(&p->device) != hipSuccess ||
+        hipDeviceGetAttribute(&p->n_cus, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || p->n_cus < 1 ||
+        hipMalloc(&p->tables, sizeof(MelTables)) != hipSuccess ||
         hipMemcpy(p->tables, h, sizeof(MelTables), hipMemcpyHostToDevice) != hipSuccess) {
         delete h;
         delete p;
@@ -193,9 +417,11 @@ extern "C" int asrk_logmel_plan_create(int n_mels, const float* mel_filters, asr
     // one-time set-up for the entry point that allocates nothing: this device's address of the static scratch array, and
     // the tile kernel's LDS opt-in (so that the first asrk_logmel_f32_noalloc call changes no function attribute either)
     void* sym = nullptr;
-    static std::atomic<uint64_t> lds_set{0};
+    static std::atomic<uint64_t> lds_set[2][4];
     if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_noalloc_clip_max)) != hipSuccess || !sym ||
-        asrk_max_lds_once((const void*)logmel_tile_kernel, (int)TILE_LDS_BYTES, lds_set) != ASRK_OK) {
+        !tile_kernel_for(n_mels, true) ||
+        asrk_max_lds_once((const void*)tile_kernel_for(n_mels, true), (int)tile_lds_bytes(MAX_MELS), lds_set[0][(n_mels + 41) / 42 - 1]) != ASRK_OK ||
+        asrk_max_lds_once((const void*)tile_kernel_for(n_mels, false), (int)tile_lds_bytes(MAX_MELS), lds_set[1][(n_mels + 41) / 42 - 1]) != ASRK_OK) {
         (void)hipFree(p->tables);
         delete p;
         return ASRK_ERR_HIP;
@@ -217,14 +443,19 @@ namespace {
 int logmel_launch(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out, unsigned* clip_max_key,
                   bool prof_ok, hipStream_t st) {
     const int n_frames = n_samples / HOP;
-    static std::atomic<uint64_t> lds_set{0};
-    if (asrk_max_lds_once((const void*)logmel_tile_kernel, (int)TILE_LDS_BYTES, lds_set) != ASRK_OK) return ASRK_ERR_HIP;
+    const auto kern = tile_kernel_for(plan->n_mels, (n_frames % 4) == 0);  // LDS opt-in: once per kernel, in plan_create
+    if (!kern) return ASRK_ERR_SHAPE;
     ASRK_CHECK_HIP(hipMemsetAsync(clip_max_key, 0, (size_t)B * 4, st));
     // algorithmic bytes: read the waveform once, write the features once
     AsrkProfScope prof(prof_ok ? ASRK_PROF_LOGMEL : -1, (double)B * ((double)n_samples * 4 + (double)plan->n_mels * n_frames * 4), st);
-    dim3 grid((n_frames + TILE_F - 1) / TILE_F, B);
-    hipLaunchKernelGGL(logmel_tile_kernel, grid, dim3(NTHREADS), TILE_LDS_BYTES, st, wave, n_samples, n_frames,
-                       plan->n_mels, plan->tables, out, clip_max_key);
+    const int tiles_per_clip = (n_frames + TILE_F - 1) / TILE_F;
+    const long n_tiles = (long)((tiles_per_clip + 3) / 4 * 4) * B;  // work items: groups of four tiles (the kernel's TGROUP)
+    if (n_tiles > 0x7fffffffL) return ASRK_ERR_SHAPE;
+    // persistent workgroups: 4 per CU (LDS and registers allow exactly that), each walks tiles b, b + grid, ...
+    const long resident = (long)LOGMEL_WPS * plan->n_cus;
+    const int grid = (int)(n_tiles < resident ? n_tiles : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), tile_lds_bytes(plan->n_mels), st, wave, n_samples,
+                       n_frames, plan->n_mels, tiles_per_clip, (int)n_tiles, plan->tables, out, clip_max_key, plan->n_chunks);
     ASRK_CHECK_HIP(hipGetLastError());
     const int per_clip = plan->n_mels * n_frames;
     if ((per_clip & 3) == 0) {
@@ -245,6 +476,7 @@ int logmel_check(const asrk_logmel_plan* plan, const float* wave, int B, int n_s
     if (B < 0 || n_samples <= NFFT / 2) return ASRK_ERR_SHAPE;
     if (((uintptr_t)out & 15) || ((uintptr_t)wave & 3)) return ASRK_ERR_ALIGN;
     if (n_samples / HOP < 1 || B > 65535) return ASRK_ERR_SHAPE;
+    if ((long)plan->n_mels * (n_samples / HOP) >= (1L << 29)) return ASRK_ERR_SHAPE;  // 32-bit byte offsets inside a clip's features
     return ASRK_OK;
 }
 }  // namespace

@@ -1,6 +1,7 @@
-// Host emulation of the log-mel kernel's paired-frame 400-point FFT (asr_amd/csrc/asrk_fft400.h):
-// walks the 16 x 20 lanes of one workgroup in loops, with the LDS images as plain arrays.
-// usage: fft400_host <in: 5360 f32 samples> <out: 32*201 f32 power>
+// Host emulation of the log-mel kernel's paired-frame 400-point FFT (asr_amd/csrc/asrk_fft400.h): walks the 64 lanes of
+// ONE wave (6 frames = 3 frame pairs of 20 lanes, lanes 60..63 shadowing lanes 40..43) through the same per-lane steps
+// as the device code, with the wave-private LDS image as a plain array and the cross-lane mirror fetch as an array
+// lookup.  usage: fft400_host <in: 1200 f32 samples> <out: 6*201 f32 power>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -8,11 +9,12 @@
 
 #include "../../asr_amd/csrc/asrk_fft400.h"
 
+
 int main(int argc, char** argv) {
     if (argc != 3) return 2;
-    std::vector<float> S(TILE_S);
+    std::vector<float> S(WAVE_S);
     FILE* f = fopen(argv[1], "rb");
-    if (!f || fread(S.data(), 4, TILE_S, f) != (size_t)TILE_S) return 3;
+    if (!f || fread(S.data(), 4, WAVE_S, f) != (size_t)WAVE_S) return 3;
     fclose(f);
     MelTables* tab = new MelTables();
     const double two_pi = 6.283185307179586476925286766559;
@@ -23,17 +25,40 @@ int main(int argc, char** argv) {
             tab->twiddle[k1 * 20 + n2].x = (float)cos(a);
             tab->twiddle[k1 * 20 + n2].y = (float)sin(a);
         }
-    std::vector<float2> Y(NGROUPS * YGROUP), E(NGROUPS * 20 * EROW);
-    std::vector<float> P(TILE_F * PSTRIDE, -1.0f);
-    static float zr[NGROUPS][20][20], zi[NGROUPS][20][20];
-    for (int g = 0; g < NGROUPS; ++g)
-        for (int j = 0; j < 20; ++j) fft400_stage1(S.data(), Y.data(), tab, g, j);
-    for (int g = 0; g < NGROUPS; ++g)
-        for (int j = 0; j < 20; ++j) fft400_stage2(Y.data(), g, j, zr[g][j], zi[g][j]);
-    for (int g = 0; g < NGROUPS; ++g)
-        for (int j = 0; j < 20; ++j) fft400_publish(E.data(), g, j, zr[g][j], zi[g][j]);
-    for (int g = 0; g < NGROUPS; ++g)
-        for (int j = 0; j < 20; ++j) fft400_power(E.data(), P.data(), g, j, zr[g][j], zi[g][j]);
+    std::vector<float> priv(PRIV_FLOATS, -7.0f);
+    static float re[64][20], im[64][20], zr[64][20], zi[64][20];
+    // stage 1, every lane (the shadow lanes 60..63 repeat lanes 40..43)
+    for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane_pair(lane), j = lane_j(lane);
+        for (int n1 = 0; n1 < 20; ++n1) {
+            re[lane][n1] = S[(2 * g) * HOP + 20 * n1 + j];
+            im[lane][n1] = S[(2 * g + 1) * HOP + 20 * n1 + j];
+        }
+        fft400_stage1(re[lane], im[lane], tab->window, tab->twiddle, j);
+    }
+    // exchange: all lanes write, then all lanes read their row -- first the real parts, then the imaginary parts
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int k1 = 0; k1 < 20; ++k1)
+                priv[xch_index(lane_pair(lane), k1, lane_j(lane))] = pass ? im[lane][k1] : re[lane][k1];
+        for (int lane = 0; lane < 64; ++lane)
+            for (int n2 = 0; n2 < 20; ++n2)
+                (pass ? zi : zr)[lane][n2] = priv[xch_index(lane_pair(lane), lane_j(lane), n2)];
+    }
+    for (int lane = 0; lane < 64; ++lane) dft20(zr[lane], zi[lane]);
+    // mirror fetch + power image [frame][bin] in the same private region
+    std::vector<float> P(FPW * PSTRIDE, -1.0f);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane_pair(lane), j = lane_j(lane), ml = mirror_lane(g, j);
+        for (int k2 = 0; k2 <= 10; ++k2) {
+            if (k2 == 10 && j != 0) continue;
+            float cr, ci;
+            if (j == 0) { cr = zr[lane][mirror_reg_lane0(k2)]; ci = zi[lane][mirror_reg_lane0(k2)]; }
+            else { cr = zr[ml][mirror_reg(k2)]; ci = zi[ml][mirror_reg(k2)]; }
+            fft400_power(zr[lane][k2], zi[lane][k2], cr, ci, P[(2 * g) * PSTRIDE + j + 20 * k2],
+                         P[(2 * g + 1) * PSTRIDE + j + 20 * k2]);
+        }
+    }
     f = fopen(argv[2], "wb");
     fwrite(P.data(), 4, P.size(), f);
     fclose(f);

@@ -227,18 +227,18 @@ def test_encoder_and_projector_parameter_contract():
 
 
 def test_fft400_host_emulation_matches_numpy(tmp_path):
-    """The kernel's paired-frame 400-point FFT index algebra, run lane by lane on the host."""
+    """The kernel's paired-frame 400-point FFT index algebra (stage 1, the 20 x 20 exchange image, stage 2, the mirror
+    lane / register of the spectrum separation), run lane by lane over one wave on the host."""
     exe = tmp_path / "fft400_host"
     subprocess.check_call(["g++", "-O2", "-o", str(exe), os.path.join(ROOT, "tests", "host", "fft400_host.cpp")])
     rng = np.random.default_rng(0)
-    s = (rng.standard_normal(5360) * 0.1).astype(np.float32)
-    s[960:1600] = 0.0  # silent frames must give exact zeros
+    s = (rng.standard_normal(1200) * 0.1).astype(np.float32)
+    s[320:880] = 0.0  # frames 2 and 3 (one pair, samples 320..879) are silent and must give exact zeros
     s.tofile(tmp_path / "s.bin")
     subprocess.check_call([str(exe), str(tmp_path / "s.bin"), str(tmp_path / "p.bin")])
-    p = np.fromfile(tmp_path / "p.bin", dtype=np.float32).reshape(32, 201)
+    p = np.fromfile(tmp_path / "p.bin", dtype=np.float32).reshape(6, -1)[:, :201]  # rows are padded to 16-byte chunks
     n = np.arange(400)
     w = 0.5 - 0.5 * np.cos(2 * np.pi * n / 400)
-    ref = np.stack([np.abs(np.fft.rfft(s[t * 160: t * 160 + 400].astype(np.float64) * w)) ** 2 for t in range(32)])
+    ref = np.stack([np.abs(np.fft.rfft(s[t * 160: t * 160 + 400].astype(np.float64) * w)) ** 2 for t in range(6)])
     assert np.abs(p - ref).max() <= 2e-6 * ref.max()
-    t_silent = [t for t in range(32) if t * 160 >= 960 and t * 160 + 400 <= 1600]
-    assert t_silent and all(np.all(p[t] == 0.0) for t in t_silent)
+    assert np.all(p[2] == 0.0) and np.all(p[3] == 0.0)
