@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASRK_LIB_PATH") or os.path.join(_HERE, "libasrk.so")
 
 ASRK_F32, ASRK_BF16, ASRK_I16 = 0, 1, 2
+(ASRK_OK, ASRK_ERR_NULL, ASRK_ERR_SHAPE, ASRK_ERR_ALIGN, ASRK_ERR_HIP, ASRK_ERR_WORKSPACE, ASRK_ERR_UNSUPPORTED,
+ ASRK_ERR_LENGTH) = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class AsrkError(RuntimeError):
@@ -40,7 +42,7 @@ class ProjectorDims(Structure):
 
 
 class ProjectorParams(Structure):
-    _fields_ = [(n, c_void_p) for n in ("gamma", "w1", "b1", "w2", "b2")]
+    _fields_ = [(n, c_void_p) for n in ("gamma", "w1", "b1", "w2", "b2", "packed")]
 
 
 class ProjectorGrads(Structure):
@@ -53,7 +55,8 @@ _SIGNATURES = {
     "asrk_strerror": (c_char_p, [c_int]),
     "asrk_logmel_plan_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
     "asrk_logmel_plan_destroy": (None, [c_void_p]),
-    "asrk_logmel_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "asrk_logmel_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "asrk_logmel_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "asrk_logmel_f32_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "asrk_encoder_create": (c_int, [POINTER(EncoderDims), POINTER(EncoderWeights), c_void_p, POINTER(c_void_p)]),
     "asrk_encoder_destroy": (None, [c_void_p]),
@@ -61,6 +64,11 @@ _SIGNATURES = {
     "asrk_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "asrk_projector_workspace_bytes": (c_size_t, [POINTER(ProjectorDims), c_int]),
     "asrk_projector_saved_bytes": (c_size_t, [POINTER(ProjectorDims), c_int]),
+    "asrk_projector_packed_bytes": (c_size_t, [POINTER(ProjectorDims)]),
+    "asrk_projector_pack": (c_int, [POINTER(ProjectorDims), POINTER(ProjectorParams), c_void_p, c_void_p]),
+    "asrk_encoder_projector_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                               POINTER(ProjectorDims), POINTER(ProjectorParams), c_void_p, c_int, c_void_p,
+                                               c_void_p, c_size_t, c_void_p]),
     "asrk_projector_forward": (c_int, [POINTER(ProjectorDims), POINTER(ProjectorParams), c_void_p, c_int, c_void_p,
                                        c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "asrk_projector_backward": (c_int, [POINTER(ProjectorDims), POINTER(ProjectorParams), c_void_p, c_int, c_int,

@@ -230,7 +230,13 @@ extern "C" void asrk_encoder_destroy(asrk_encoder* enc) {
 
 extern "C" int asrk_encoder_forward(const asrk_encoder* enc, const float* feats, int B, int n_frames, float* out,
                                     void* ws, size_t ws_bytes, void* stream) {
-    if (!enc || !feats || !out || !ws) return ASRK_ERR_NULL;
+    if (!out) return ASRK_ERR_NULL;
+    return asrk_encoder_forward_impl(enc, feats, B, n_frames, out, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int asrk_encoder_forward_impl(const asrk_encoder* enc, const float* feats, int B, int n_frames, float* out,
+                              const AsrkRmsTail* tail, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!enc || !feats || !ws || (!out && !tail)) return ASRK_ERR_NULL;
     if (n_frames != T_IN) return ASRK_ERR_LENGTH;
     if (B <= 0 || B > 65535) return ASRK_ERR_SHAPE;
     if (((uintptr_t)feats & 15) || ((uintptr_t)out & 15) || ((uintptr_t)ws & 255)) return ASRK_ERR_ALIGN;
@@ -238,7 +244,6 @@ extern "C" int asrk_encoder_forward(const asrk_encoder* enc, const float* feats,
     const int d = dm.d_model, F = dm.ffn_dim, C = dm.n_mels, H = dm.n_heads;
     const WsLayout wl = ws_layout(dm, B);
     if (ws_bytes < wl.total) return ASRK_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     bf16_t* featT = (bf16_t*)(w + wl.featT);
     bf16_t* h1 = (bf16_t*)(w + wl.h1);
@@ -293,7 +298,10 @@ extern "C" int asrk_encoder_forward(const asrk_encoder* enc, const float* feats,
     // layer's ln1, or the encoder's final norm): the add is exact in fp32, only the delta is rounded to bf16,
     // like every other GEMM operand on this path.
     const size_t nl = enc->layers.size();
-    if (nl == 0) return asrk_launch_layernorm(resid, enc->lnw, enc->lnb, out, false, M, d, 1e-5f, st);
+    if (nl == 0) {
+        if (tail) return asrk_launch_layernorm_rms(resid, nullptr, enc->lnw, enc->lnb, out, *tail, M, d, 1e-5f, st);
+        return asrk_launch_layernorm(resid, enc->lnw, enc->lnb, out, false, M, d, 1e-5f, st);
+    }
     if ((rc = asrk_launch_layernorm(resid, enc->layers[0].ln1w, enc->layers[0].ln1b, xn, true, M, d, 1e-5f, st)) != ASRK_OK)
         return rc;
     for (size_t i = 0; i < nl; ++i) {
@@ -307,6 +315,8 @@ extern "C" int asrk_encoder_forward(const asrk_encoder* enc, const float* feats,
         if (i + 1 < nl) {
             const LayerPacked& Ln = enc->layers[i + 1];
             rc = asrk_launch_add_layernorm(resid, delta, Ln.ln1w, Ln.ln1b, xn, true, true, M, d, 1e-5f, st);
+        } else if (tail) {
+            rc = asrk_launch_layernorm_rms(resid, delta, enc->lnw, enc->lnb, out, *tail, M, d, 1e-5f, st);
         } else {
             rc = asrk_launch_add_layernorm(resid, delta, enc->lnw, enc->lnb, out, false, false, M, d, 1e-5f, st);
         }

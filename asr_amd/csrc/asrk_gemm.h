@@ -97,8 +97,23 @@ int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* 
                           float eps, hipStream_t st);
 int asrk_launch_add_layernorm(float* x, const bf16_t* delta, const float* w, const float* b, void* out, bool out_bf16,
                               bool keep_x, int M, int D, float eps, hipStream_t st);
+// The projector's RMSNorm fused behind the encoder's last LayerNorm (asrk_norm.hip: layernorm_rms_kernel)
+struct AsrkRmsTail {
+    const float* gamma;  // norm.weight of the projector
+    bf16_t* xn;          // [M][D] bf16: gamma * y * rstd, the operand of linear_1
+    float* rstd;         // [M] or null
+    float eps;
+};
+// x (+ delta, may be null) -> LayerNorm -> y (written to y_out unless null) -> RMSNorm -> t.xn, t.rstd
+int asrk_launch_layernorm_rms(const float* x, const bf16_t* delta, const float* w, const float* b, float* y_out,
+                              const AsrkRmsTail& t, int M, int D, float eps, hipStream_t st);
 int asrk_launch_rmsnorm_bf16(const float* x, const float* gamma, bf16_t* xn, float* rstd, int M, int D, float eps,
                              hipStream_t st);
 int asrk_launch_cast_f32_bf16(const float* src, bf16_t* dst, size_t n, float scale, hipStream_t st);
 // q_log2e: q carries an extra factor log2(e) (folded into W_q / b_q by the caller)
+// asrk_encoder.hip: the encoder forward; with `tail` its last norm also produces the projector's RMSNorm output and
+// `out` (last_hidden_state, fp32) may be null
+struct asrk_encoder;
+int asrk_encoder_forward_impl(const asrk_encoder* enc, const float* feats, int B, int n_frames, float* out,
+                              const AsrkRmsTail* tail, void* ws, size_t ws_bytes, hipStream_t st);
 int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, bool q_log2e, hipStream_t st);

@@ -81,6 +81,8 @@ constexpr size_t tile_lds_bytes(int n_mels) {
 static_assert(tile_lds_bytes(MAX_MELS) <= 163840 / 4, "four workgroups per CU");
 
 constexpr int LOGMEL_WPS = 4;  // workgroups per CU (= waves per SIMD)
+constexpr int KEY_STRIDE = 32;  // words between the per-clip maximum keys: one 128-byte line each (see store_tile)
+constexpr int FIN_TILES = 4;    // tiles per workgroup of the finish kernel
 // ROW_ITERS = ceil(n_mels / 42): the store pass is unrolled by it, so that the number of global stores per tile is known
 // at compile time.  A wave's vector-memory operations complete in issue order and the next tile's sample loads are
 // issued BEFORE this tile's stores; with a countable number of stores the compiler waits for those loads with
@@ -90,7 +92,8 @@ template <int ROW_ITERS, bool VEC>
 __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const float* __restrict__ wave, int n_samples, int n_frames,
                                                                    int n_mels, int tiles_per_clip, int n_tiles,
                                                                    const MelTables* __restrict__ tab, float* __restrict__ out,
-                                                                   unsigned* __restrict__ clip_max_key, int n_chunks) {
+                                                                   unsigned* __restrict__ clip_max_key, float* __restrict__ tile_min,
+                                                                   int n_chunks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Lwin = reinterpret_cast<float*>(smem + OFF_WIN);
     float2* Ltw = reinterpret_cast<float2*>(smem + OFF_TW);
@@ -158,50 +161,81 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
         }
     };
 
-    // The store pass of a tile: its [n_mels][24] values from the staging image as whole 96-byte row segments (a per-element
-    // path when rows are not 16-byte aligned), and the per-clip maximum.  It is branch-free on purpose -- buffer stores with
-    // the out-of-range lanes pointed past the end of the clip's buffer, which the hardware drops -- so that every wave
-    // issues exactly ROW_ITERS (x 4) stores + 1 atomic per tile and the compiler can COUNT them: it runs at the top of the
-    // NEXT tile, right behind that tile's sample loads, and the wait for those loads is then vmcnt(stores + 1), not
-    // vmcnt(0).  A wave's vector-memory operations complete in issue order; with the store pass at the end of its own tile
-    // every wave sat out the write latency of its stores once per tile in front of its next loads (0.14 of 0.49 ms).
+    // The store pass of a tile: its [n_mels][24] values from the staging image, (x + 4) / 4 applied, as whole 96-byte row
+    // segments (a per-element path when rows are not 16-byte aligned), plus the wave's minimum for the finish kernel and
+    // its share of the per-clip maximum.  It is branch-free on purpose -- buffer stores with the out-of-range lanes pointed
+    // past the end of the buffer, which the hardware drops -- so that every wave issues exactly ROW_ITERS (x 4) + 1 stores
+    // per tile and the compiler can COUNT them: the pass runs at the top of the NEXT tile, right behind that tile's sample
+    // loads, and the wait for those loads is then vmcnt(stores), not vmcnt(0).  A wave's vector-memory operations
+    // complete in issue order; with the store pass at the end of its own tile every wave sat out the write latency of its
+    // stores once per tile in front of its next loads (0.14 of 0.49 ms).
+    //
+    // The per-clip maximum is kept in a register while the wave stays on one clip and merged into the clip's key (an
+    // ordered-integer atomicMax) only when the clip changes and at the end: integer atomics at agent scope execute at the
+    // memory side, ONE AFTER THE OTHER PER 64-BYTE LINE at ~12 ns each, and the wave's next loads queue behind them.  One
+    // atomic per wave and tile into keys packed 16 to a line cost ~0.1 ms per call whatever the batch (tools/
+    // logmel_bsweep.sh: 97 us for 8 clips against 15 us for 1); hence also one key per 128-byte line (KEY_STRIDE).
+    float run_max = -INFINITY;
+    int run_clip = -1;
+    auto flush_max = [&]() {
+        if (run_clip >= 0 && lane == 0) atomicMax(clip_max_key + (size_t)run_clip * KEY_STRIDE, ordered_key(run_max));
+    };
+    const __amdgpu_buffer_rsrc_t rs_min = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(tile_min), 0, tile_min ? n_clips * tiles_per_clip * NWAVES * 4 : 0, 0x00020000);  // none: all dropped
     auto store_tile = [&](int tile_or_none) {
         // tile_or_none < 0 (a workgroup's first pass): the same instructions with every lane out of range, so that the
         // loop body has ONE instruction stream -- a branch around the stores would bring back the uncountable case
         const bool valid = tile_or_none >= 0;
         const int tile = valid ? tile_or_none : 0;
         const int clip = __builtin_amdgcn_readfirstlane(item_clip(tile));
-        const int t0 = item_tile(tile) * TILE_F;
+        const int tt = item_tile(tile);
+        const int t0 = tt * TILE_F;
         const int per_clip = n_mels * n_frames;  // < 2^29 elements (host check)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(uniform_ptr(reinterpret_cast<const char*>(out + (size_t)clip * per_clip))), 0, per_clip * 4, 0x00020000);
         const int c4 = tid % 6, r0 = tid / 6;
         const int fr = t0 + 4 * c4;
-        float vmax = -INFINITY;
+        float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
         for (int it = 0; it < ROW_ITERS; ++it) {
             const int r = r0 + 42 * it;
             const bool row_ok = valid && tid < 42 * 6 && r < n_mels;
             const float4 v = *reinterpret_cast<const float4*>(stage + (row_ok ? r : 0) * TILE_F + 4 * c4);
             const int off = (r * n_frames + fr) * 4;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            float y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = (e[k] + 4.0f) * 0.25f;
             if (VEC) {  // n_frames % 4 == 0: a float4 is valid or invalid as a whole
                 const bool ok = row_ok && fr < n_frames;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ok ? off : 0x7fffffff, 0, 0);
-                const float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-                vmax = ok ? fmaxf(vmax, m4) : vmax;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, float4{y[0], y[1], y[2], y[3]}), rs,
+                                                       ok ? off : 0x7fffffff, 0, 0);
+                vmax = ok ? fmaxf(vmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))) : vmax;
+                vmin = ok ? fminf(vmin, fminf(fminf(v.x, v.y), fminf(v.z, v.w))) : vmin;
             } else {
-                const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool ok = row_ok && fr + k < n_frames;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[k]), rs, ok ? off + 4 * k : 0x7fffffff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[k]), rs, ok ? off + 4 * k : 0x7fffffff, 0, 0);
                     vmax = ok ? fmaxf(vmax, e[k]) : vmax;
+                    vmin = ok ? fminf(vmin, e[k]) : vmin;
                 }
             }
         }
         vmax = wave_max(vmax);
-        // unconditional (countable): a wave without a valid value contributes the key of -inf, below every real one
-        if (lane == 0) atomicMax(clip_max_key + clip, ordered_key(vmax));
+        vmin = -wave_max(-vmin);
+        // this wave's minimum (log10 units, +inf when it stored nothing) of the tile: slot [clip][tile][wave]
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vmin), rs_min,
+                                              valid && lane == 0 ? ((clip * tiles_per_clip + tt) * NWAVES + wv) * 4 : 0x7fffffff, 0, 0);
+        if (valid) {  // wave-uniform
+            if (clip != run_clip) {
+                flush_max();
+                run_clip = clip;
+                run_max = vmax;
+            } else {
+                run_max = fmaxf(run_max, vmax);
+            }
+        }
     };
 
     float re[20], im[20];
@@ -310,13 +344,14 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
         LSTAMP(6);  // barrier: staging complete
     }
     if (prev_tile >= 0) store_tile(prev_tile);
+    flush_max();
 #ifdef ASRK_STAMPS
     if (tid == 0 && blockIdx.x < 1024)
         for (int i = 0; i < 10; ++i) g_lm_stamps[blockIdx.x * 16 + i] = lm_acc[i];
 #endif
 }
 
-using tile_kernel_t = void (*)(const float*, int, int, int, int, int, const MelTables*, float*, unsigned*, int);
+using tile_kernel_t = void (*)(const float*, int, int, int, int, int, const MelTables*, float*, unsigned*, float*, int);
 // vec: rows of the output are 16-byte aligned (n_frames % 4 == 0): float4 stores
 tile_kernel_t tile_kernel_for(int n_mels, bool vec) {
     switch ((n_mels + 41) / 42) {
@@ -328,35 +363,53 @@ tile_kernel_t tile_kernel_for(int n_mels, bool vec) {
     }
 }
 
+// Kernel 2: the per-clip floor max(y, ((clip_max - 8) + 4) / 4) in place -- the same value, bit for bit, as
+// (max(x, clip_max - 8) + 4) / 4 (HF :163-165), since x -> (x + 4) / 4 is monotone.  One workgroup per (clip, group of four
+// tiles = 96 frames = 384-byte row segments); it leaves at once when none of the 16 wave minima of its tiles is below
+// the floor, which is every group of a clip without silence -- then this pass reads 64 bytes per group instead of
+// rewriting the features (0.07 of 0.43 ms per 256 clips).  tile_min == nullptr (the no-alloc entry point): no shortcut.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ out, const unsigned* __restrict__ key,
-                                                             int per_clip) {
-    const int clip = blockIdx.y;
-    const float floor_v = ordered_value(key[clip]) - 8.0f;
-    float* o = out + (size_t)clip * per_clip;
-    if (VEC4) {  // per_clip % 4 == 0: every clip base is 16-byte aligned
-        const int n4 = per_clip >> 2;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-            float4 v = reinterpret_cast<float4*>(o)[i];
-            v.x = (fmaxf(v.x, floor_v) + 4.0f) * 0.25f;
-            v.y = (fmaxf(v.y, floor_v) + 4.0f) * 0.25f;
-            v.z = (fmaxf(v.z, floor_v) + 4.0f) * 0.25f;
-            v.w = (fmaxf(v.w, floor_v) + 4.0f) * 0.25f;
-            reinterpret_cast<float4*>(o)[i] = v;
+                                                             const float* __restrict__ tile_min, int n_mels, int n_frames,
+                                                             int tiles_per_clip) {
+    const int clip = blockIdx.y, grp = blockIdx.x;
+    const float floor_x = ordered_value(key[(size_t)clip * KEY_STRIDE]) - 8.0f;
+    if (tile_min) {
+        const int t_lo = grp * FIN_TILES, t_hi = min(t_lo + FIN_TILES, tiles_per_clip);
+        float m = INFINITY;
+        for (int i = t_lo * NWAVES + (int)threadIdx.x; i < t_hi * NWAVES; i += 256)
+            m = fminf(m, tile_min[(size_t)clip * tiles_per_clip * NWAVES + i]);
+        if (!__syncthreads_or(m < floor_x)) return;
+    }
+    const float floor_y = (floor_x + 4.0f) * 0.25f;
+    float* o = out + (size_t)clip * n_mels * n_frames;
+    const int f_lo = grp * FIN_TILES * TILE_F, f_hi = min(f_lo + FIN_TILES * TILE_F, n_frames);
+    if (VEC4) {  // n_frames % 4 == 0: rows and segments are 16-byte aligned
+        const int w4 = (f_hi - f_lo) >> 2;  // float4 per row segment (24 for a whole group)
+        for (int i = threadIdx.x; i < n_mels * w4; i += 256) {
+            const int r = i / w4, c = i - r * w4;
+            float4* q = reinterpret_cast<float4*>(o + (size_t)r * n_frames + f_lo) + c;
+            float4 v = *q;
+            v.x = fmaxf(v.x, floor_y); v.y = fmaxf(v.y, floor_y); v.z = fmaxf(v.z, floor_y); v.w = fmaxf(v.w, floor_y);
+            *q = v;
         }
     } else {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_clip; i += gridDim.x * blockDim.x)
-            o[i] = (fmaxf(o[i], floor_v) + 4.0f) * 0.25f;
+        const int w = f_hi - f_lo;
+        for (int i = threadIdx.x; i < n_mels * w; i += 256) {
+            const int r = i / w, c = i - r * w;
+            float* q = o + (size_t)r * n_frames + f_lo + c;
+            *q = fmaxf(*q, floor_y);
+        }
     }
 }
 
 }  // namespace
 
-// Scratch of asrk_logmel_f32_noalloc: the per-clip maxima (ordered-integer keys), one word per clip.  In host code this
+// Scratch of asrk_logmel_f32_noalloc: the per-clip maxima (ordered-integer keys), one 128-byte line per clip (512 KiB).  In host code this
 // name is only a stand-in for the symbol, not a device address: every device has its own copy at its own address, which
 // asrk_logmel_plan_create looks up once (hipGetSymbolAddress, with the plan's device current) and keeps in the plan;
 // kernels and hipMemsetAsync only ever get that pointer.
-static __device__ __align__(256) unsigned g_noalloc_clip_max[ASRK_LOGMEL_NOALLOC_MAX_CLIPS];
+static __device__ __align__(256) unsigned g_noalloc_clip_max[ASRK_LOGMEL_NOALLOC_MAX_CLIPS * KEY_STRIDE];
 
 struct asrk_logmel_plan {
     int n_mels;
@@ -441,35 +494,35 @@ namespace {
 // Both entry points: clear the per-clip maxima, tile kernel, finish kernel.  `prof`: bracket with events when the
 // measurement hook is on (event creation allocates, so the no-alloc entry point never does).
 int logmel_launch(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out, unsigned* clip_max_key,
-                  bool prof_ok, hipStream_t st) {
+                  float* tile_min, bool prof_ok, hipStream_t st) {
     const int n_frames = n_samples / HOP;
     const auto kern = tile_kernel_for(plan->n_mels, (n_frames % 4) == 0);  // LDS opt-in: once per kernel, in plan_create
     if (!kern) return ASRK_ERR_SHAPE;
-    ASRK_CHECK_HIP(hipMemsetAsync(clip_max_key, 0, (size_t)B * 4, st));
+    ASRK_CHECK_HIP(hipMemsetAsync(clip_max_key, 0, (size_t)B * KEY_STRIDE * 4, st));
     // algorithmic bytes: read the waveform once, write the features once
     AsrkProfScope prof(prof_ok ? ASRK_PROF_LOGMEL : -1, (double)B * ((double)n_samples * 4 + (double)plan->n_mels * n_frames * 4), st);
     const int tiles_per_clip = (n_frames + TILE_F - 1) / TILE_F;
     const long n_tiles = (long)((tiles_per_clip + 3) / 4 * 4) * B;  // work items: groups of four tiles (the kernel's TGROUP)
-    if (n_tiles > 0x7fffffffL) return ASRK_ERR_SHAPE;
+    if (n_tiles > 0x7fffffffL / (NWAVES * 4)) return ASRK_ERR_SHAPE;
     // persistent workgroups: 4 per CU (LDS and registers allow exactly that), each walks tiles b, b + grid, ...
     const long resident = (long)LOGMEL_WPS * plan->n_cus;
     const int grid = (int)(n_tiles < resident ? n_tiles : resident);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), tile_lds_bytes(plan->n_mels), st, wave, n_samples,
-                       n_frames, plan->n_mels, tiles_per_clip, (int)n_tiles, plan->tables, out, clip_max_key, plan->n_chunks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), tile_lds_bytes(plan->n_mels), st, wave, n_samples, n_frames,
+                       plan->n_mels, tiles_per_clip, (int)n_tiles, plan->tables, out, clip_max_key, tile_min, plan->n_chunks);
     ASRK_CHECK_HIP(hipGetLastError());
-    const int per_clip = plan->n_mels * n_frames;
-    if ((per_clip & 3) == 0) {
-        int gx = (per_clip / 4 + 255) / 256;
-        gx = gx > 64 ? 64 : gx;
-        hipLaunchKernelGGL(logmel_finish_kernel<true>, dim3(gx, B), dim3(256), 0, st, out, clip_max_key, per_clip);
-    } else {
-        int gx = (per_clip + 255) / 256;
-        gx = gx > 64 ? 64 : gx;
-        hipLaunchKernelGGL(logmel_finish_kernel<false>, dim3(gx, B), dim3(256), 0, st, out, clip_max_key, per_clip);
-    }
+    const dim3 fgrid((tiles_per_clip + FIN_TILES - 1) / FIN_TILES, B);
+    if ((n_frames & 3) == 0)
+        hipLaunchKernelGGL(logmel_finish_kernel<true>, fgrid, dim3(256), 0, st, out, clip_max_key, tile_min, plan->n_mels, n_frames,
+                           tiles_per_clip);
+    else
+        hipLaunchKernelGGL(logmel_finish_kernel<false>, fgrid, dim3(256), 0, st, out, clip_max_key, tile_min, plan->n_mels, n_frames,
+                           tiles_per_clip);
     ASRK_CHECK_HIP(hipGetLastError());
     return ASRK_OK;
 }
+
+// workspace of asrk_logmel_f32: keys [B][KEY_STRIDE] | tile minima [B][tiles_per_clip][NWAVES]
+size_t ws_keys_bytes(int B) { return ((size_t)B * KEY_STRIDE * 4 + 255) / 256 * 256; }
 
 int logmel_check(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, const float* out) {
     if (!plan || !wave || !out) return ASRK_ERR_NULL;
@@ -481,13 +534,22 @@ int logmel_check(const asrk_logmel_plan* plan, const float* wave, int B, int n_s
 }
 }  // namespace
 
-extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out,
-                               float* clip_max_ws, void* stream) {
-    if (!clip_max_ws) return ASRK_ERR_NULL;
+extern "C" size_t asrk_logmel_workspace_bytes(int B, int n_samples) {
+    if (B <= 0 || n_samples < HOP) return 0;
+    const int tiles_per_clip = (n_samples / HOP + TILE_F - 1) / TILE_F;
+    return ws_keys_bytes(B) + (size_t)B * tiles_per_clip * NWAVES * 4;
+}
+
+extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out, void* ws,
+                               size_t ws_bytes, void* stream) {
     const int rc = logmel_check(plan, wave, B, n_samples, out);
     if (rc != ASRK_OK) return rc;
     if (B == 0) return ASRK_OK;
-    return logmel_launch(plan, wave, B, n_samples, out, reinterpret_cast<unsigned*>(clip_max_ws), true, (hipStream_t)stream);
+    if (!ws) return ASRK_ERR_NULL;
+    if ((uintptr_t)ws & 255) return ASRK_ERR_ALIGN;
+    if (ws_bytes < asrk_logmel_workspace_bytes(B, n_samples)) return ASRK_ERR_WORKSPACE;
+    return logmel_launch(plan, wave, B, n_samples, out, static_cast<unsigned*>(ws),
+                         reinterpret_cast<float*>(static_cast<char*>(ws) + ws_keys_bytes(B)), true, (hipStream_t)stream);
 }
 
 // The variant that allocates nothing (include/asrk.h): the per-clip maxima live in this device's copy of
@@ -501,5 +563,6 @@ extern "C" int asrk_logmel_f32_noalloc(const asrk_logmel_plan* plan, const float
     if (hipGetDevice(&dev) != hipSuccess) return ASRK_ERR_HIP;
     if (dev != plan->device || !plan->noalloc_scratch) return ASRK_ERR_UNSUPPORTED;  // the scratch address is per device
     if (B == 0) return ASRK_OK;
-    return logmel_launch(plan, wave, B, n_samples, out, plan->noalloc_scratch, false, (hipStream_t)stream);
+    // no tile minima (they would need 2 KiB per clip of scratch): the finish kernel then visits every group
+    return logmel_launch(plan, wave, B, n_samples, out, plan->noalloc_scratch, nullptr, false, (hipStream_t)stream);
 }

@@ -112,6 +112,82 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     }
 }
 
+// The encoder -> projector hand-off in one pass over the row (SURVEY 8 a8 + a9's prologue): x += delta, y = the encoder's
+// final LayerNorm of it (HF modeling_whisper.py:642), then the projector's LlamaRMSNorm of y (src/modeling.py:78) emitted
+// as the bf16 operand of linear_1, with its rstd for the backward.  y itself (last_hidden_state, fp32) is written only
+// when the caller wants it (`y_out`: the training path keeps it for d gamma); without it the 4 bytes/element write and
+// the RMSNorm's 4 bytes/element re-read are gone.  Same arithmetic, in the same order, as the two separate kernels.
+template <bool ADD>
+__global__ __launch_bounds__(256) void layernorm_rms_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ y_out, const float* __restrict__ gamma,
+                                                            bf16_t* __restrict__ xn, float* __restrict__ rstd_out, int M, int D,
+                                                            float eps, float rms_eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    float4 v[MAX_V4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (size_t)row * D) + c);
+            f32x4 sum = xv;
+            if (ADD) {
+                const bf16x4 dv = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(delta + (size_t)row * D) + c);
+                sum = xv + f32x4{(float)dv[0], (float)dv[1], (float)dv[2], (float)dv[3]};
+            }
+            v[i] = float4{sum[0], sum[1], sum[2], sum[3]};
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[c];
+            const float4 bb = reinterpret_cast<const float4*>(b)[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            if (y_out) reinterpret_cast<float4*>(y_out + (size_t)row * D)[c] = o;
+            v[i] = o;
+            q2 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+        }
+    }
+    const float rstd2 = rsqrtf(wave_sum(q2) / (float)D + rms_eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd2;
+#pragma unroll
+    for (int i = 0; i < MAX_V4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+            bf16x4 p;
+            p[0] = (bf16_t)(g.x * (v[i].x * rstd2));
+            p[1] = (bf16_t)(g.y * (v[i].y * rstd2));
+            p[2] = (bf16_t)(g.z * (v[i].z * rstd2));
+            p[3] = (bf16_t)(g.w * (v[i].w * rstd2));
+            reinterpret_cast<bf16x4*>(xn + (size_t)row * D)[c] = p;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                             size_t n4, float scale) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -158,6 +234,25 @@ int asrk_launch_add_layernorm(float* x, const bf16_t* delta, const float* w, con
         hipLaunchKernelGGL((layernorm_kernel<false, true, true>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
     else
         hipLaunchKernelGGL((layernorm_kernel<false, true, false>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+int asrk_launch_layernorm_rms(const float* x, const bf16_t* delta, const float* w, const float* b, float* y_out,
+                              const AsrkRmsTail& t, int M, int D, float eps, hipStream_t st) {
+    if (!x || !w || !b || !t.gamma || !t.xn) return ASRK_ERR_NULL;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAX_V4) return ASRK_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)delta & 7) || ((uintptr_t)w & 15) || ((uintptr_t)b & 15) || ((uintptr_t)y_out & 15) ||
+        ((uintptr_t)t.gamma & 15) || ((uintptr_t)t.xn & 7))
+        return ASRK_ERR_ALIGN;
+    const dim3 grid((M + 3) / 4);
+    // algorithmic bytes per element: x read 4 (+ delta read 2) (+ y write 4) + xn write 2
+    AsrkProfScope prof(ASRK_PROF_NORM, (double)M * D * (6.0 + (delta ? 2.0 : 0.0) + (y_out ? 4.0 : 0.0)), st);
+    if (delta)
+        hipLaunchKernelGGL((layernorm_rms_kernel<true>), grid, dim3(256), 0, st, x, delta, w, b, y_out, t.gamma, t.xn, t.rstd, M, D,
+                           eps, t.eps);
+    else
+        hipLaunchKernelGGL((layernorm_rms_kernel<false>), grid, dim3(256), 0, st, x, delta, w, b, y_out, t.gamma, t.xn, t.rstd, M, D,
+                           eps, t.eps);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
 

@@ -6,7 +6,8 @@
 // RMSNorm follows HF LlamaRMSNorm (transformers/models/llama/modeling_llama.py:62-67).
 // GEMMs run in bf16 on MFMA with fp32 accumulation (what the reference gets under accelerate's
 // bf16 autocast); statistics, bias/gamma gradients and every reduction are fp32.  fp32 master
-// weights are cast to bf16 at each call (1.7 M parameters: negligible next to the activations).
+// weights are cast to bf16 (and transposed for the backward) by asrk_projector_pack into a buffer the caller keeps until
+// the parameters change; without one (params->packed NULL) every call makes its own copies in the workspace.
 //
 // saved (for backward), M rows:  rstd f32 [M] | xn bf16 [M][A] | pre bf16 [M][T] | h bf16 [M][T]
 #include "asrk_common.h"
@@ -232,6 +233,20 @@ unsigned grid_for(size_t n, unsigned cap = 8192) {
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+// bf16 copies of the weights: W1 [T][A] | W2 [T][T] | W1^T [A][T] | W2^T [T][T]
+struct PackedLayout { size_t w1, w2, w1T, w2T, total; };
+PackedLayout packed_layout(int A, int T) {
+    PackedLayout p;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off = align_up(off + b, 256); return o; };
+    p.w1 = take((size_t)T * A * 2);
+    p.w2 = take((size_t)T * T * 2);
+    p.w1T = take((size_t)A * T * 2);
+    p.w2T = take((size_t)T * T * 2);
+    p.total = off;
+    return p;
+}
+
 GemmArgs plain_gemm(const bf16_t* X, int64_t ldx, const bf16_t* W, void* out, int64_t ldo, int M, int N, int K) {
     GemmArgs a{};
     a.X = X; a.W = W; a.out = out;
@@ -254,32 +269,79 @@ extern "C" size_t asrk_projector_saved_bytes(const asrk_projector_dims* d, int M
     return saved_layout(d->audio_dim, d->text_dim, M).total;
 }
 
-extern "C" int asrk_projector_forward(const asrk_projector_dims* d, const asrk_projector_params* p, const float* x, int M,
-                                      void* out, int out_dtype, void* saved, void* ws, size_t ws_bytes, void* stream) {
+extern "C" size_t asrk_projector_packed_bytes(const asrk_projector_dims* d) {
+    if (check_dims(d, 1) != ASRK_OK) return 0;
+    return packed_layout(d->audio_dim, d->text_dim).total;
+}
+
+extern "C" int asrk_projector_pack(const asrk_projector_dims* d, const asrk_projector_params* p, void* packed, void* stream) {
+    int rc = check_dims(d, 1);
+    if (rc != ASRK_OK) return rc;
+    if (!p || !packed || !p->w1 || !p->w2) return ASRK_ERR_NULL;
+    if ((uintptr_t)packed & 255) return ASRK_ERR_ALIGN;
+    const int A = d->audio_dim, T = d->text_dim;
+    const PackedLayout pl = packed_layout(A, T);
+    hipStream_t st = (hipStream_t)stream;
+    char* b = (char*)packed;
+    if ((rc = asrk_launch_cast_f32_bf16(p->w1, (bf16_t*)(b + pl.w1), (size_t)T * A, 1.f, st)) != ASRK_OK) return rc;
+    if ((rc = asrk_launch_cast_f32_bf16(p->w2, (bf16_t*)(b + pl.w2), (size_t)T * T, 1.f, st)) != ASRK_OK) return rc;
+    hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((T + 63) / 64, (A + 63) / 64), dim3(256), 0, st, p->w1, (bf16_t*)(b + pl.w1T), T, A);
+    hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((T + 63) / 64, (T + 63) / 64), dim3(256), 0, st, p->w2, (bf16_t*)(b + pl.w2T), T, T);
+    return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
+}
+
+namespace {
+
+int forward_check(const asrk_projector_dims* d, const asrk_projector_params* p, int M, const void* out, int out_dtype,
+                  const void* saved, const void* ws, size_t ws_bytes) {
     int rc = check_dims(d, M);
     if (rc != ASRK_OK) return rc;
-    if (!p || !x || !out || !ws || !p->gamma || !p->w1 || !p->b1 || !p->w2 || !p->b2) return ASRK_ERR_NULL;
+    if (!p || !out || !ws || !p->gamma || !p->w1 || !p->b1 || !p->w2 || !p->b2) return ASRK_ERR_NULL;
     if (out_dtype != ASRK_F32 && out_dtype != ASRK_BF16) return ASRK_ERR_UNSUPPORTED;
-    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)ws & 255) || ((uintptr_t)saved & 255)) return ASRK_ERR_ALIGN;
-    const int A = d->audio_dim, T = d->text_dim;
-    const WsLayout wl = ws_layout(A, T, M);
-    if (ws_bytes < wl.total) return ASRK_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    char* w = (char*)ws;
-    bf16_t* w1 = (bf16_t*)(w + wl.w1);
-    bf16_t* w2 = (bf16_t*)(w + wl.w2);
-    if ((rc = asrk_launch_cast_f32_bf16(p->w1, w1, (size_t)T * A, 1.f, st)) != ASRK_OK) return rc;
-    if ((rc = asrk_launch_cast_f32_bf16(p->w2, w2, (size_t)T * T, 1.f, st)) != ASRK_OK) return rc;
-    bf16_t *xn, *pre = nullptr, *h;
-    float* rstd = nullptr;
+    if (((uintptr_t)out & 15) || ((uintptr_t)ws & 255) || ((uintptr_t)saved & 255) || ((uintptr_t)p->packed & 255)) return ASRK_ERR_ALIGN;
+    if (ws_bytes < ws_layout(d->audio_dim, d->text_dim, M).total) return ASRK_ERR_WORKSPACE;
+    return ASRK_OK;
+}
+
+// where this call's RMSNorm output lives: in `saved` when the backward will want it, else in the workspace
+void xn_slot(int A, int T, int M, void* saved, void* ws, bf16_t** xn, float** rstd) {
     if (saved) {
         const SavedLayout sl = saved_layout(A, T, M);
-        char* s = (char*)saved;
-        rstd = (float*)(s + sl.rstd); xn = (bf16_t*)(s + sl.xn); pre = (bf16_t*)(s + sl.pre); h = (bf16_t*)(s + sl.h);
+        *rstd = (float*)((char*)saved + sl.rstd);
+        *xn = (bf16_t*)((char*)saved + sl.xn);
     } else {
-        xn = (bf16_t*)(w + wl.xn); h = (bf16_t*)(w + wl.h);
+        *rstd = nullptr;
+        *xn = (bf16_t*)((char*)ws + ws_layout(A, T, M).xn);
     }
-    if ((rc = asrk_launch_rmsnorm_bf16(x, p->gamma, xn, rstd, M, A, RMS_EPS, st)) != ASRK_OK) return rc;
+}
+
+// linear_1 -> GELU -> linear_2 -> * 0.01 from the RMSNorm output already sitting in its slot (arguments checked)
+int forward_from_xn(const asrk_projector_dims* d, const asrk_projector_params* p, int M, void* out, int out_dtype, void* saved,
+                    void* ws, hipStream_t st) {
+    const int A = d->audio_dim, T = d->text_dim;
+    const WsLayout wl = ws_layout(A, T, M);
+    char* w = (char*)ws;
+    int rc;
+    const bf16_t *w1, *w2;
+    if (p->packed) {
+        const PackedLayout pl = packed_layout(A, T);
+        w1 = (const bf16_t*)((const char*)p->packed + pl.w1);
+        w2 = (const bf16_t*)((const char*)p->packed + pl.w2);
+    } else {
+        if ((rc = asrk_launch_cast_f32_bf16(p->w1, (bf16_t*)(w + wl.w1), (size_t)T * A, 1.f, st)) != ASRK_OK) return rc;
+        if ((rc = asrk_launch_cast_f32_bf16(p->w2, (bf16_t*)(w + wl.w2), (size_t)T * T, 1.f, st)) != ASRK_OK) return rc;
+        w1 = (const bf16_t*)(w + wl.w1);
+        w2 = (const bf16_t*)(w + wl.w2);
+    }
+    bf16_t *xn, *pre = nullptr, *h;
+    float* rstd;
+    xn_slot(A, T, M, saved, ws, &xn, &rstd);
+    if (saved) {
+        const SavedLayout sl = saved_layout(A, T, M);
+        pre = (bf16_t*)((char*)saved + sl.pre); h = (bf16_t*)((char*)saved + sl.h);
+    } else {
+        h = (bf16_t*)(w + wl.h);
+    }
     GemmArgs g1 = plain_gemm(xn, A, w1, saved ? (void*)pre : (void*)h, T, M, T, A);
     g1.bias = p->b1;
     if (saved) {
@@ -297,6 +359,43 @@ extern "C" int asrk_projector_forward(const asrk_projector_dims* d, const asrk_p
     return asrk_gemm_launch(g2, false, out_dtype == ASRK_BF16, st);
 }
 
+}  // namespace
+
+extern "C" int asrk_projector_forward(const asrk_projector_dims* d, const asrk_projector_params* p, const float* x, int M,
+                                      void* out, int out_dtype, void* saved, void* ws, size_t ws_bytes, void* stream) {
+    int rc = forward_check(d, p, M, out, out_dtype, saved, ws, ws_bytes);
+    if (rc != ASRK_OK) return rc;
+    if (!x) return ASRK_ERR_NULL;
+    if ((uintptr_t)x & 15) return ASRK_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    bf16_t* xn;
+    float* rstd;
+    xn_slot(d->audio_dim, d->text_dim, M, saved, ws, &xn, &rstd);
+    if ((rc = asrk_launch_rmsnorm_bf16(x, p->gamma, xn, rstd, M, d->audio_dim, RMS_EPS, st)) != ASRK_OK) return rc;
+    return forward_from_xn(d, p, M, out, out_dtype, saved, ws, st);
+}
+
+// Encoder and projector in one call: the encoder's last LayerNorm hands the projector its RMSNorm output directly
+// (asrk_norm.hip: layernorm_rms_kernel).  `hidden` (last_hidden_state, fp32 [B*1500][d_model]) is written only when
+// non-NULL; a caller that will run asrk_projector_backward needs it (that call's `x`).
+extern "C" int asrk_encoder_projector_forward(const asrk_encoder* enc, const float* feats, int B, int n_frames, float* hidden,
+                                              void* enc_ws, size_t enc_ws_bytes, const asrk_projector_dims* d,
+                                              const asrk_projector_params* p, void* out, int out_dtype, void* saved, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    if (B <= 0 || B > 65535) return ASRK_ERR_SHAPE;
+    const int M = B * 1500;
+    int rc = forward_check(d, p, M, out, out_dtype, saved, ws, ws_bytes);
+    if (rc != ASRK_OK) return rc;
+    if (saved && !hidden) return ASRK_ERR_NULL;  // the backward reads the projector's fp32 input
+    hipStream_t st = (hipStream_t)stream;
+    AsrkRmsTail tail;
+    tail.gamma = p->gamma;
+    tail.eps = RMS_EPS;
+    xn_slot(d->audio_dim, d->text_dim, M, saved, ws, &tail.xn, &tail.rstd);
+    if ((rc = asrk_encoder_forward_impl(enc, feats, B, n_frames, hidden, &tail, enc_ws, enc_ws_bytes, st)) != ASRK_OK) return rc;
+    return forward_from_xn(d, p, M, out, out_dtype, saved, ws, st);
+}
+
 extern "C" int asrk_projector_backward(const asrk_projector_dims* d, const asrk_projector_params* p, const void* grad_out,
                                        int grad_dtype, int M, const void* saved, const asrk_projector_grads* grads,
                                        float* grad_x, const float* x, void* ws, size_t ws_bytes, void* stream) {
@@ -307,7 +406,7 @@ extern "C" int asrk_projector_backward(const asrk_projector_dims* d, const asrk_
         return ASRK_ERR_NULL;
     if (grad_dtype != ASRK_F32 && grad_dtype != ASRK_BF16) return ASRK_ERR_UNSUPPORTED;
     if (((uintptr_t)grad_out & 15) || ((uintptr_t)ws & 255) || ((uintptr_t)saved & 255) || ((uintptr_t)x & 15) ||
-        ((uintptr_t)grad_x & 15))
+        ((uintptr_t)grad_x & 15) || ((uintptr_t)p->packed & 255))
         return ASRK_ERR_ALIGN;
     const int A = d->audio_dim, T = d->text_dim;
     const WsLayout wl = ws_layout(A, T, M);
@@ -324,8 +423,17 @@ extern "C" int asrk_projector_backward(const asrk_projector_dims* d, const asrk_
     bf16_t* dyT = (bf16_t*)(w + wl.dyT);
     bf16_t* hT = (bf16_t*)(w + wl.hT);
     bf16_t* xnT = (bf16_t*)(w + wl.xnT);
-    bf16_t* w2T = (bf16_t*)(w + wl.w2T);
-    bf16_t* w1T = (bf16_t*)(w + wl.w1T);
+    const bf16_t *w2T, *w1T;
+    if (p->packed) {
+        const PackedLayout pl = packed_layout(A, T);
+        w1T = (const bf16_t*)((const char*)p->packed + pl.w1T);
+        w2T = (const bf16_t*)((const char*)p->packed + pl.w2T);
+    } else {
+        hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((T + 63) / 64, (T + 63) / 64), dim3(256), 0, st, p->w2, (bf16_t*)(w + wl.w2T), T, T);
+        hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((T + 63) / 64, (A + 63) / 64), dim3(256), 0, st, p->w1, (bf16_t*)(w + wl.w1T), T, A);
+        w2T = (const bf16_t*)(w + wl.w2T);
+        w1T = (const bf16_t*)(w + wl.w1T);
+    }
     bf16_t* dpre = (bf16_t*)(w + wl.dpre);
     bf16_t* dxn = (bf16_t*)(w + wl.dxn);
     float* slabs = (float*)(w + wl.slabs);
@@ -362,7 +470,6 @@ extern "C" int asrk_projector_backward(const asrk_projector_dims* d, const asrk_
     if (hipGetLastError() != hipSuccess) return ASRK_ERR_HIP;
     if ((rc = wgrad(dyT, hT, T, T, grads->w2)) != ASRK_OK) return rc;
     // 3. d pre = (dy W2) * gelu'(pre)
-    hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((T + 63) / 64, (T + 63) / 64), dim3(256), 0, st, p->w2, w2T, T, T);
     {
         GemmArgs g = plain_gemm(dy, T, w2T, dpre, T, M, T, T);
         g.dg_pre = pre;
@@ -376,7 +483,6 @@ extern "C" int asrk_projector_backward(const asrk_projector_dims* d, const asrk_
     if (hipGetLastError() != hipSuccess) return ASRK_ERR_HIP;
     if ((rc = wgrad(dyT, xnT, T, A, grads->w1)) != ASRK_OK) return rc;
     // 5. d xn = dpre W1;  d gamma = sum_rows dxn * xhat;  optional d x
-    hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((T + 63) / 64, (A + 63) / 64), dim3(256), 0, st, p->w1, w1T, T, A);
     {
         GemmArgs g = plain_gemm(dpre, T, w1T, dxn, A, M, A, T);
         if ((rc = asrk_gemm_launch(g, false, true, st)) != ASRK_OK) return rc;

@@ -89,6 +89,8 @@ class WhisperEncoder(nn.Module):
         self.whisper.eval()
         self._handle = None
         self._packed_key = None
+        self._packed_sentinel = None
+        self._stale = True
         self._ws = None
 
     # ------------------------------------------------------------------ weights
@@ -105,11 +107,36 @@ class WhisperEncoder(nn.Module):
         m.whisper.encoder.load_state_dict({k[len(prefix):]: v for k, v in tgt.items()}, strict=True)
         return m.to(device)
 
+    # The packed bf16 copy follows the fp32 parameters through everything that replaces or rewrites them wholesale --
+    # .to() / .cuda() / .float() (``_apply``) and ``load_state_dict`` mark it stale -- and through in-place edits of
+    # the two sentinel parameters checked on every call (the first and the last one).  The full (address, version) key
+    # over all ~200-500 parameters costs 0.2-1.2 ms of host time per forward, so it is taken only when one of those
+    # says something changed; after an in-place edit of some OTHER frozen weight call ``refresh_weights()``.
+    def _apply(self, fn, *args, **kwargs):
+        self._stale = True
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._stale = True
+        return super().load_state_dict(*args, **kwargs)
+
+    def refresh_weights(self):
+        """Re-pack the frozen weights on the next forward (needed only after editing them in place)."""
+        self._stale = True
+
+    def _sentinel(self):
+        enc = self.whisper.encoder
+        a, b = enc.conv1.weight, enc.layer_norm.bias
+        return (a.data_ptr(), a._version, b.data_ptr(), b._version)
+
     def _pack(self):
+        if self._handle is not None and not self._stale and self._sentinel() == self._packed_sentinel:
+            return self._handle
         enc = self.whisper.encoder
         params = list(enc.parameters())
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._handle is not None and key == self._packed_key:
+            self._stale, self._packed_sentinel = False, self._sentinel()
             return self._handle
         dev = params[0].device
         if dev.type != "cuda":
@@ -149,6 +176,7 @@ class WhisperEncoder(nn.Module):
                                                ctypes.byref(handle)), "asrk_encoder_create")
             torch.cuda.current_stream().synchronize()  # packing kernels have read the fp32 sources
         self._handle, self._packed_key = handle, key
+        self._stale, self._packed_sentinel = False, self._sentinel()
         return handle
 
     def _release(self):
@@ -165,6 +193,18 @@ class WhisperEncoder(nn.Module):
     # ------------------------------------------------------------------ forward (src/modeling.py:33-40)
     def forward(self, input_features: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         # attention_mask is accepted and ignored, exactly as HF does (modeling_whisper.py:607-609, 636-640)
+        with torch.no_grad():
+            x, handle, ws = self._prepare(input_features)
+            B = x.shape[0]
+            out = torch.empty((B, 1500, self.d_model), dtype=torch.float32, device=x.device)
+            if B == 0:
+                return out
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().asrk_encoder_forward(handle, _lib.ptr(x), B, 3000, _lib.ptr(out), _lib.ptr(ws),
+                                                            ws.numel(), _lib.current_stream()), "asrk_encoder_forward")
+            return out
+
+    def _check_features(self, input_features: torch.Tensor):
         if input_features.shape[-1] != 3000:
             raise ValueError(
                 f"Whisper expects the mel input features to be of length 3000, but found "
@@ -172,20 +212,19 @@ class WhisperEncoder(nn.Module):
             )
         if input_features.dim() != 3 or input_features.shape[1] != self.n_mels:
             raise ValueError(f"expected input_features of shape [batch, {self.n_mels}, 3000]")
+
+    def _prepare(self, input_features: torch.Tensor):
+        """Checked fp32 features on the encoder's device, the packed-weights handle and a workspace for this batch
+        (shared by ``forward`` and ``asr_amd.projector.encode_and_project``)."""
+        self._check_features(input_features)
         with torch.no_grad():
             handle = self._pack()
             dev = self.whisper.encoder.conv1.weight.device
             x = input_features.to(device=dev, dtype=torch.float32).contiguous()
             B = x.shape[0]
-            out = torch.empty((B, 1500, self.d_model), dtype=torch.float32, device=dev)
-            if B == 0:
-                return out
-            lib = _lib.load()
             with torch.cuda.device(dev):
-                need = lib.asrk_encoder_workspace_bytes(handle, B)
+                need = _lib.load().asrk_encoder_workspace_bytes(handle, max(B, 1))
                 if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
                     self._ws = None
                     self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-                _lib.check(lib.asrk_encoder_forward(handle, _lib.ptr(x), B, 3000, _lib.ptr(out), _lib.ptr(self._ws),
-                                                    self._ws.numel(), _lib.current_stream()), "asrk_encoder_forward")
-            return out
+            return x, handle, self._ws

@@ -146,9 +146,9 @@ class LogMelFeatureExtractor:
         lib = _lib.load()
         with torch.cuda.device(wave.device):
             out = torch.empty((B, self.feature_size, L // self.hop_length), dtype=torch.float32, device=wave.device)
-            ws = torch.empty((max(B, 1),), dtype=torch.float32, device=wave.device)
+            ws = torch.empty((max(int(lib.asrk_logmel_workspace_bytes(B, L)), 256),), dtype=torch.uint8, device=wave.device)
             _lib.check(lib.asrk_logmel_f32(self._plan(wave.device), _lib.ptr(wave), B, L, _lib.ptr(out),
-                                           _lib.ptr(ws), _lib.current_stream()), "asrk_logmel_f32")
+                                           _lib.ptr(ws), ws.numel(), _lib.current_stream()), "asrk_logmel_f32")
         return out
 
     # ------------------------------------------------------------------ __call__ (HF :193-346)

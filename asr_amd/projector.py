@@ -27,8 +27,9 @@ class _RMSNormParams(nn.Module):
         self.variance_epsilon = eps
 
 
-def _params_struct(gamma, w1, b1, w2, b2):
-    return _lib.ProjectorParams(*[ctypes.c_void_p(t.data_ptr()) for t in (gamma, w1, b1, w2, b2)])
+def _params_struct(gamma, w1, b1, w2, b2, packed=None):
+    return _lib.ProjectorParams(*[ctypes.c_void_p(t.data_ptr()) for t in (gamma, w1, b1, w2, b2)],
+                                ctypes.c_void_p(packed.data_ptr() if packed is not None else None))
 
 
 _WS = {}
@@ -42,32 +43,78 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+class _PackedWeights:
+    """The bf16 copies of linear_1 / linear_2 (and their transposes for the backward) made by
+    ``asrk_projector_pack``, kept until a parameter changes: the key is (storage address, ``_version``)
+    of both weights, which every in-place update (an optimizer step, ``load_state_dict``, ``.to()``)
+    changes.  The reference gets the same reuse from autocast's weight-cast cache."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+
+    def get(self, lib, dims, w1, w2, ps) -> torch.Tensor:
+        key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, w1.device, w1.dtype)
+        if key != self.key:
+            if self.buf is None or self.buf.device != ps[1].device:
+                self.buf = torch.empty((lib.asrk_projector_packed_bytes(ctypes.byref(dims)),), dtype=torch.uint8,
+                                       device=ps[1].device)
+            pstruct = _params_struct(*ps)
+            _lib.check(lib.asrk_projector_pack(ctypes.byref(dims), ctypes.byref(pstruct), _lib.ptr(self.buf),
+                                               _lib.current_stream()), "asrk_projector_pack")
+            self.key = key
+        return self.buf
+
+
 class _ProjectorFn(torch.autograd.Function):
+    """``x`` is the projector's input, or -- with ``encoder`` given -- the encoder's ``input_features``:
+    then both run in one ``asrk_encoder_projector_forward`` call and ``last_hidden_state`` exists only
+    if the backward will need it."""
+
     @staticmethod
-    def forward(ctx, x, gamma, w1, b1, w2, b2, out_dtype, grad_enabled):
+    def forward(ctx, x, gamma, w1, b1, w2, b2, out_dtype, grad_enabled, cache, encoder):
         lib = _lib.load()
         A, T = w1.shape[1], w1.shape[0]
-        x2 = x.detach().reshape(-1, A).to(torch.float32).contiguous()
-        M = x2.shape[0]
         dims = _lib.ProjectorDims(A, T)
         ps = [t.detach().to(torch.float32).contiguous() for t in (gamma, w1, b1, w2, b2)]
-        need_grad = grad_enabled and any(ctx.needs_input_grad[:6])  # no saved activations under no_grad
-        out = torch.empty((M, T), dtype=out_dtype, device=x2.device)
-        with torch.cuda.device(x2.device):
-            ws = _workspace(x2.device, lib.asrk_projector_workspace_bytes(ctypes.byref(dims), M))
+        need_grad = grad_enabled and any(ctx.needs_input_grad[1:6])  # no saved activations under no_grad
+        if encoder is None:
+            x2 = x.detach().reshape(-1, A).to(torch.float32).contiguous()
+            out_shape = (*x.shape[:-1], T)
+            need_grad = need_grad or (grad_enabled and ctx.needs_input_grad[0])
+        else:
+            feats, handle, enc_ws = encoder._prepare(x)
+            out_shape = (feats.shape[0], 1500, T)
+            x2 = torch.empty((feats.shape[0] * 1500, A), dtype=torch.float32, device=feats.device) if need_grad else None
+        dev = ps[1].device
+        M = out_shape[0] * 1500 if encoder is not None else x2.shape[0]
+        out = torch.empty((M, T), dtype=out_dtype, device=dev)
+        if M == 0:
+            return out.reshape(out_shape)
+        with torch.cuda.device(dev):
+            packed = cache.get(lib, dims, w1, w2, ps) if cache is not None else None
+            ws = _workspace(dev, lib.asrk_projector_workspace_bytes(ctypes.byref(dims), M))
             saved = None
             if need_grad:
-                saved = torch.empty((lib.asrk_projector_saved_bytes(ctypes.byref(dims), M),), dtype=torch.uint8,
-                                    device=x2.device)
-            pstruct = _params_struct(*ps)
-            _lib.check(lib.asrk_projector_forward(ctypes.byref(dims), ctypes.byref(pstruct), _lib.ptr(x2), M,
-                                                  _lib.ptr(out), _DT[out_dtype], _lib.ptr(saved), _lib.ptr(ws),
-                                                  ws.numel(), _lib.current_stream()), "asrk_projector_forward")
+                saved = torch.empty((lib.asrk_projector_saved_bytes(ctypes.byref(dims), M),), dtype=torch.uint8, device=dev)
+            pstruct = _params_struct(*ps, packed=packed)
+            if encoder is None:
+                _lib.check(lib.asrk_projector_forward(ctypes.byref(dims), ctypes.byref(pstruct), _lib.ptr(x2), M,
+                                                      _lib.ptr(out), _DT[out_dtype], _lib.ptr(saved), _lib.ptr(ws),
+                                                      ws.numel(), _lib.current_stream()), "asrk_projector_forward")
+            else:
+                _lib.check(lib.asrk_encoder_projector_forward(handle, _lib.ptr(feats), feats.shape[0], 3000, _lib.ptr(x2),
+                                                              _lib.ptr(enc_ws), enc_ws.numel(), ctypes.byref(dims),
+                                                              ctypes.byref(pstruct), _lib.ptr(out), _DT[out_dtype],
+                                                              _lib.ptr(saved), _lib.ptr(ws), ws.numel(),
+                                                              _lib.current_stream()), "asrk_encoder_projector_forward")
         if need_grad:
             ctx.save_for_backward(x2, saved, *ps)
+            ctx.packed = packed  # valid in the backward: autograd forbids in-place changes of saved parameters
             ctx.dims = (A, T, M)
             ctx.x_shape = x.shape
-        return out.reshape(*x.shape[:-1], T)
+            ctx.fused = encoder is not None
+        return out.reshape(out_shape)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -81,16 +128,16 @@ class _ProjectorFn(torch.autograd.Function):
         go = go.contiguous()
         dev = x2.device
         g = [torch.empty_like(t) for t in (gamma, w1, b1, w2, b2)]
-        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gx = torch.empty_like(x2) if (ctx.needs_input_grad[0] and not ctx.fused) else None
         with torch.cuda.device(dev):
             ws = _workspace(dev, lib.asrk_projector_workspace_bytes(ctypes.byref(dims), M))
-            pstruct = _params_struct(gamma, w1, b1, w2, b2)
+            pstruct = _params_struct(gamma, w1, b1, w2, b2, packed=ctx.packed)
             gstruct = _lib.ProjectorGrads(*[ctypes.c_void_p(t.data_ptr()) for t in g])
             _lib.check(lib.asrk_projector_backward(ctypes.byref(dims), ctypes.byref(pstruct), _lib.ptr(go), _DT[go.dtype],
                                                    M, _lib.ptr(saved), ctypes.byref(gstruct), _lib.ptr(gx), _lib.ptr(x2),
                                                    _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                        "asrk_projector_backward")
-        return (gx.reshape(ctx.x_shape) if gx is not None else None, g[0], g[1], g[2], g[3], g[4], None, None)
+        return (gx.reshape(ctx.x_shape) if gx is not None else None, g[0], g[1], g[2], g[3], g[4], None, None, None, None)
 
 
 class AudioProjector(nn.Module):
@@ -106,13 +153,28 @@ class AudioProjector(nn.Module):
         nn.init.normal_(self.linear_2.weight)
         nn.init.zeros_(self.linear_2.bias)
         self.out_dtype = out_dtype  # None: fp32, or bf16 under torch.autocast(bfloat16) like the reference
+        self._packed = _PackedWeights()
+
+    def _out_dtype(self):
+        if self.out_dtype is not None:
+            return self.out_dtype
+        return torch.bfloat16 if (torch.is_autocast_enabled() and
+                                  torch.get_autocast_gpu_dtype() == torch.bfloat16) else torch.float32
+
+    def _apply_fn(self, x, encoder):
+        if self.linear_1.weight.device.type != "cuda":
+            raise _lib.AsrkError("AudioProjector runs on a ROCm GPU only (there is no CPU fallback); call .to('cuda')")
+        return _ProjectorFn.apply(x, self.norm.weight, self.linear_1.weight, self.linear_1.bias, self.linear_2.weight,
+                                  self.linear_2.bias, self._out_dtype(), torch.is_grad_enabled(), self._packed, encoder)
 
     def forward(self, audio_features: torch.Tensor) -> torch.Tensor:
         if not audio_features.is_cuda:
             raise _lib.AsrkError("AudioProjector runs on a ROCm GPU only (there is no CPU fallback)")
-        out_dtype = self.out_dtype
-        if out_dtype is None:
-            out_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and
-                                           torch.get_autocast_gpu_dtype() == torch.bfloat16) else torch.float32
-        return _ProjectorFn.apply(audio_features, self.norm.weight, self.linear_1.weight, self.linear_1.bias,
-                                  self.linear_2.weight, self.linear_2.bias, out_dtype, torch.is_grad_enabled())
+        return self._apply_fn(audio_features, None)
+
+
+def encode_and_project(encoder, projector: AudioProjector, input_features: torch.Tensor) -> torch.Tensor:
+    """``projector(encoder(input_features))`` (src/modeling.py:213-220, :296-301) as ONE library call: the encoder's
+    final LayerNorm feeds the projector's RMSNorm directly and ``last_hidden_state`` is materialised only when the
+    projector is being trained (its backward reads it).  Same values, bit for bit, as the two separate modules."""
+    return projector._apply_fn(input_features, encoder)

@@ -78,6 +78,12 @@ def synth_audio(batch, rank, device):
     return t.contiguous()
 
 
+def encode_and_project(enc, proj, feats):
+    from asr_amd.projector import encode_and_project as fused
+
+    return fused(enc, proj, feats)
+
+
 def seeded_models(w, device):
     from asr_amd.encoder import WhisperEncoder
     from asr_amd.projector import AudioProjector
@@ -355,7 +361,7 @@ def main():
 
         def step():
             feats = features()
-            emb = proj(enc(feats))  # the encoder wrapper runs under no_grad (src/modeling.py:33-40)
+            emb = encode_and_project(enc, proj, feats)  # the encoder runs under no_grad (src/modeling.py:33-40)
             if reducer is not None:
                 reducer.zero_()  # .grad tensors are views of the reducer's flat buffer
             else:
@@ -377,7 +383,7 @@ def main():
         def step():
             with torch.no_grad():
                 feats = features()
-                return proj(enc(feats))
+                return encode_and_project(enc, proj, feats)
 
     def barrier():
         if on_gpu:

@@ -61,16 +61,19 @@ void asrk_logmel_plan_destroy(asrk_logmel_plan* plan);
 
 /* wave  dev f32 [B][n_samples]   (already padded/truncated, :300-307; n_samples > 200)
  * out   dev f32 [B][n_mels][n_samples/160]
- * clip_max_ws dev f32 [B] scratch for the per-clip maximum (:160-162).
+ * ws    dev scratch of asrk_logmel_workspace_bytes(B, n_samples), 256-byte aligned: the per-clip maxima (:160-162),
+ *       one 128-byte line per clip, and one minimum per wave and tile, by which the floor pass skips what needs none.
  * STFT is Hann-400 / hop-160 / center + reflect pad; the last STFT frame is dropped (:154). */
+size_t asrk_logmel_workspace_bytes(int B, int n_samples);
 int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples,
-                    float* out, float* clip_max_ws, void* stream);
+                    float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* The same computation for callers that cannot allocate -- code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  It has NO counterpart in the reference (which never manages device memory itself).
- * The per-clip maxima, which asrk_logmel_f32 keeps in the caller's `clip_max_ws`, live in a static device array of
- * ASRK_LOGMEL_NOALLOC_MAX_CLIPS words (16 KiB, held by every GPU the library runs on until the process ends) whose
- * per-device address asrk_logmel_plan_create looks up once.  The call itself performs no hipMalloc / hipFree / event
+ * The per-clip maxima, which asrk_logmel_f32 keeps in the caller's `ws`, live in a static device array of
+ * ASRK_LOGMEL_NOALLOC_MAX_CLIPS 128-byte lines (512 KiB, held by every GPU the library runs on until the process ends)
+ * whose per-device address asrk_logmel_plan_create looks up once; the per-tile minima are not kept, so the floor pass
+ * visits every tile (same result, bit for bit).  The call itself performs no hipMalloc / hipFree / event
  * creation and is not timed by the measurement hook.  B > ASRK_LOGMEL_NOALLOC_MAX_CLIPS returns ASRK_ERR_WORKSPACE;
  * a plan created on another device returns ASRK_ERR_UNSUPPORTED.  All calls on one GPU share that array: calls
  * that overlap on one GPU (two streams, two threads) race -- serialise them, or use asrk_logmel_f32 with separate
@@ -132,6 +135,8 @@ typedef struct {
 
 typedef struct {
     const float *gamma, *w1, *b1, *w2, *b2; /* dev fp32 master params: norm.weight, linear_{1,2}.{weight,bias} */
+    const void* packed; /* dev buffer written by asrk_projector_pack for THESE w1 / w2, or NULL: the call then makes
+                           its own bf16 copies (two casts in forward, two transposes in backward, every call) */
 } asrk_projector_params;
 
 typedef struct {
@@ -140,6 +145,13 @@ typedef struct {
 
 size_t asrk_projector_workspace_bytes(const asrk_projector_dims* dims, int M);
 size_t asrk_projector_saved_bytes(const asrk_projector_dims* dims, int M);
+
+/* The bf16 operands of the four GEMMs that read a weight (W1, W2 for the forward; W1^T, W2^T for the backward) in one
+ * caller-owned device buffer of asrk_projector_packed_bytes(), 256-byte aligned.  The fp32 parameters stay the master
+ * copy (the optimizer of src/train.py updates them): pack again after every update, never for a frozen projector.
+ * The reference gets the same copies from autocast's weight-cast cache (torch.autocast(cache_enabled=True)). */
+size_t asrk_projector_packed_bytes(const asrk_projector_dims* dims);
+int asrk_projector_pack(const asrk_projector_dims* dims, const asrk_projector_params* p, void* packed, void* stream);
 
 /* x dev f32 [M][audio_dim]; out dev [M][text_dim] in out_dtype (ASRK_F32 | ASRK_BF16).
  * saved: dev buffer of asrk_projector_saved_bytes() kept for backward, or NULL for inference. */
@@ -154,6 +166,17 @@ int asrk_projector_backward(const asrk_projector_dims* dims, const asrk_projecto
                             const void* grad_out, int grad_dtype, int M, const void* saved,
                             const asrk_projector_grads* grads, float* grad_x, const float* x, void* ws,
                             size_t ws_bytes, void* stream);
+
+/* Encoder and projector in one call (src/modeling.py:213-220 / :296-301: self.projector(self.encoder(...)) followed by
+ * the cast to the decoder's dtype): the encoder's final LayerNorm (HF modeling_whisper.py:642) also applies the
+ * projector's RMSNorm and emits the bf16 operand of linear_1, so last_hidden_state makes no round trip through HBM.
+ * `hidden` dev f32 [B][1500][d_model] receives last_hidden_state when non-NULL; it must be given when `saved` is (it is
+ * asrk_projector_backward's `x`).  enc_ws / ws: the two workspaces of the separate calls; out / saved as in
+ * asrk_projector_forward with M = 1500 B.  Results are bit-identical to asrk_encoder_forward + asrk_projector_forward. */
+int asrk_encoder_projector_forward(const asrk_encoder* enc, const float* feats, int B, int n_frames, float* hidden,
+                                   void* enc_ws, size_t enc_ws_bytes, const asrk_projector_dims* dims,
+                                   const asrk_projector_params* p, void* out, int out_dtype, void* saved, void* ws,
+                                   size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Building blocks (exported so the parity tests can check each kernel on its own through the

@@ -251,3 +251,118 @@ def test_pipeline_end_to_end_against_oracle():
     err = rel_l2(emb.cpu().numpy(), ref)
     print(f"pipeline rel-L2 {err:.3e}")
     assert err <= REL
+
+
+# ------------------------------------------------------------------------- fused hand-off, weight caches
+@pytest.mark.parametrize("enc_case, proj_case", [("tiny", "p128"), ("small", "p768")])
+def test_fused_encoder_projector_is_bit_identical_to_the_two_modules(enc_case, proj_case):
+    """asrk_encoder_projector_forward (the encoder's final LayerNorm feeding the projector's RMSNorm in one kernel) vs
+    asrk_encoder_forward + asrk_projector_forward: same arithmetic in the same order, so bit for bit -- inference
+    (no last_hidden_state at all), autocast bf16 output, and training (gradients included)."""
+    from asr_amd.projector import encode_and_project
+
+    enc, _, c = build_encoder(enc_case)
+    proj, _, pc = build_projector(proj_case)
+    assert c["d_model"] == pc["audio_dim"]
+    x = torch.from_numpy(mg.encoder_features(enc_case)).cuda()
+    with torch.no_grad():
+        two = proj(enc(x))
+        one = encode_and_project(enc, proj, x)
+        assert one.dtype == torch.float32 and tuple(one.shape) == (x.shape[0], 1500, pc["text_dim"])
+        assert torch.equal(one, two)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            one_bf, two_bf = encode_and_project(enc, proj, x), proj(enc(x))
+        assert one_bf.dtype == torch.bfloat16 and torch.equal(one_bf, two_bf)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    gy = torch.randn(tuple(two.shape), device="cuda", generator=g) * 1e-2
+    y2 = proj(enc(x))
+    y2.backward(gy)
+    ref = {n: p.grad.clone() for n, p in proj.named_parameters()}
+    proj.zero_grad(set_to_none=True)
+    y1 = encode_and_project(enc, proj, x)
+    assert y1.requires_grad and torch.equal(y1, y2)
+    y1.backward(gy)
+    for n, p in proj.named_parameters():
+        assert torch.equal(p.grad, ref[n]), n
+
+
+def test_fused_call_through_the_c_abi_checks_its_arguments():
+    import ctypes
+    from asr_amd import _lib
+    from asr_amd.projector import _params_struct
+
+    lib = _lib.load()
+    enc, _, c = build_encoder("tiny")
+    proj, _, pc = build_projector("p128")
+    x = torch.from_numpy(mg.encoder_features("tiny")).cuda()
+    feats, handle, enc_ws = enc._prepare(x)
+    B, M = feats.shape[0], feats.shape[0] * 1500
+    dims = _lib.ProjectorDims(pc["audio_dim"], pc["text_dim"])
+    ps = [p.detach() for p in (proj.norm.weight, proj.linear_1.weight, proj.linear_1.bias, proj.linear_2.weight, proj.linear_2.bias)]
+    pstruct = _params_struct(*ps)
+    ws = torch.empty((lib.asrk_projector_workspace_bytes(ctypes.byref(dims), M),), dtype=torch.uint8, device="cuda")
+    saved = torch.empty((lib.asrk_projector_saved_bytes(ctypes.byref(dims), M),), dtype=torch.uint8, device="cuda")
+    out = torch.empty((M, pc["text_dim"]), device="cuda")
+
+    def call(hidden=None, saved_=None, frames=3000, ws_bytes=None, enc_bytes=None):
+        return lib.asrk_encoder_projector_forward(handle, _lib.ptr(feats), B, frames, _lib.ptr(hidden), _lib.ptr(enc_ws),
+                                                  enc_ws.numel() if enc_bytes is None else enc_bytes, ctypes.byref(dims),
+                                                  ctypes.byref(pstruct), _lib.ptr(out), _lib.ASRK_F32, _lib.ptr(saved_),
+                                                  _lib.ptr(ws), ws.numel() if ws_bytes is None else ws_bytes,
+                                                  _lib.current_stream())
+
+    assert call() == 0
+    assert call(saved_=saved) == _lib.ASRK_ERR_NULL  # training needs last_hidden_state for the backward
+    assert call(frames=2999) == _lib.ASRK_ERR_LENGTH
+    assert call(ws_bytes=ws.numel() - 256) == _lib.ASRK_ERR_WORKSPACE
+    assert call(enc_bytes=enc_ws.numel() // 2) == _lib.ASRK_ERR_WORKSPACE
+    hidden = torch.empty((M, pc["audio_dim"]), device="cuda")
+    assert call(hidden=hidden, saved_=saved) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(hidden.reshape(B, 1500, -1), enc(x))  # last_hidden_state, when asked for, is the encoder's output
+
+
+def test_projector_packed_weights_follow_parameter_updates():
+    """The bf16 weight copies are cached on (address, _version) of linear_1 / linear_2: an optimizer-style in-place
+    update, load_state_dict and .to() must all be seen; an unchanged module must not re-pack."""
+    proj, sd, c = build_projector("p128")
+    x = torch.from_numpy(mg.projector_inputs("p128")[0]).cuda()
+    with torch.no_grad():
+        y0 = proj(x)
+        buf0, key0 = proj._packed.buf, proj._packed.key
+        assert buf0 is not None and torch.equal(proj(x), y0) and proj._packed.key == key0  # steady state: no re-pack
+        proj.linear_2.weight.mul_(2.0)  # in-place update, as an optimizer step does
+        y1 = proj(x)
+        assert proj._packed.key != key0
+        # linear_2 doubled: y1 = 2 * (y0 - 0.01 b2) + 0.01 b2, up to the bf16 rounding of W2 (exact for a factor 2)
+        b2 = proj.linear_2.bias * 0.01
+        assert torch.allclose(y1, 2.0 * (y0 - b2) + b2, rtol=0, atol=1e-6 * float(y0.abs().max()) + 1e-7)
+        proj.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        assert torch.equal(proj(x), y0)
+    # the training path uses the same copies (forward W1, W2; backward their transposes): compare with a fresh module
+    fresh, _, _ = build_projector("p128")
+    gy = torch.from_numpy(mg.projector_inputs("p128")[1]).cuda()
+    for m in (proj, fresh):
+        m.zero_grad(set_to_none=True)
+        m(x).backward(gy)
+    for (n, a), (_, b) in zip(proj.named_parameters(), fresh.named_parameters()):
+        assert torch.equal(a.grad, b.grad), n
+
+
+def test_encoder_repacks_after_weight_changes():
+    enc, sd, c = build_encoder("tiny")
+    x = torch.from_numpy(mg.encoder_features("tiny")).cuda()
+    y0 = enc(x)
+    h0 = enc._handle
+    assert torch.equal(enc(x), y0) and enc._handle is h0  # steady state: the packed copy is reused
+    with torch.no_grad():
+        enc.whisper.encoder.layer_norm.bias.add_(1.0)  # a sentinel parameter: seen without help
+    y1 = enc(x)
+    assert torch.allclose(y1, y0 + 1.0, atol=1e-5)
+    with torch.no_grad():
+        enc.whisper.encoder.layers[0].fc1.bias.zero_()  # some other frozen weight, edited in place
+    enc.refresh_weights()
+    y2 = enc(x)
+    assert not torch.equal(y2, y1)
+    enc.whisper.encoder.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    assert torch.equal(enc(x), y0)  # load_state_dict rewrites every parameter in place, sentinels included
