@@ -32,26 +32,33 @@ constexpr int TILE_F = FPW * NWAVES;                 // 24 frames per workgroup 
 constexpr int NTHREADS = 64 * NWAVES;                // 256
 constexpr int WAVE_S = (FPW - 1) * HOP + NFFT;       // 1200 samples under a wave's 6 frames
 constexpr int XPAIR = 400;                           // floats per pair of the exchange image [k1][j], dense
-constexpr int PSTRIDE = 204;                         // floats per frame of the power image: bins 0..200 + 3 zeros (16-byte chunks)
-constexpr int PRIV_FLOATS = FPW * PSTRIDE;           // wave-private LDS: max(exchange image 3 * 400, power image 6 * 204)
+constexpr int PBINS = 204;                           // bins per frame of the power image: 0..200 + 3 zeros (whole 4-bin chunks)
+constexpr int PPAIR = 424;                           // floats per pair of the power image [bin][2 frames]: 408 + 16, so that the
+                                                     // 8-byte writes of the pairs in one half-wave fall on disjoint banks
+constexpr int PRIV_FLOATS = PAIRS * PPAIR;           // wave-private LDS: max(exchange image 3 * 400, power image 3 * 424)
 constexpr int MAX_MELS = 128;
-constexpr int MAX_NNZ = 792;                         // chunked weights: 4 + 644 (80 mels) / 4 + 784 (128 mels) for the slaney banks
-static_assert(PRIV_FLOATS >= PAIRS * XPAIR && PRIV_FLOATS % 4 == 0, "private region");
+constexpr int MAX_NNZ = 12 * 20 * 4;                 // weights [step][list][4]
+static_assert(PRIV_FLOATS >= PAIRS * XPAIR && PRIV_FLOATS % 4 == 0 && PPAIR >= 2 * PBINS && PPAIR % 4 == 0, "private region");
 
-constexpr int MEL_LANES = 10;                        // lanes per frame in the mel projection (6 frames x 10 = 60 lanes)
-constexpr int MAX_CHUNKS = 24;                       // chunks per mel lane, at most (20 / 24 for the slaney banks)
+constexpr int MEL_LANES = 20;                        // lanes per frame PAIR in the mel projection (3 pairs x 20 = 60 lanes)
+constexpr int MAX_CHUNKS = 12;                       // chunks per mel lane, at most (10 / 10 for the slaney banks)
 
 // The slaney bank by rows, sparse, cut into 16-byte chunks on the bin grid: filter m covers the bins lo..hi, i.e. the
-// chunks lo / 4 .. hi / 4 of 4 bins each, with zero weights outside lo..hi.  Mel lane q owns the filters q, q + 10,
-// q + 20, ... and walks ONE flat list of chunks (the same length for every q, padded with all-zero chunks), so the
-// projection is a loop with a wave-uniform trip count, two ds_read_b128 per chunk and no per-filter control flow:
-// mel_chunk[e * 10 + q] = chunk of bins | chunk of mel_w << 6 | filter << 14 | (last chunk of its filter) << 21.
+// chunks lo / 4 .. hi / 4 of 4 bins each, with zero weights outside lo..hi.  The power image holds the two frames of a
+// pair side by side, [bin][2], so a mel lane = (frame pair, list q of filters) multiplies one weight chunk into both
+// frames: per chunk one descriptor, one ds_read_b128 of 4 weights and two of 4 bins x 2 frames, 4 packed FMAs.  The
+// filters are dealt to the 20 lists so that the lists are equally long (longest first onto the shortest list: 9 / 10
+// chunks for the 80 / 128-filter slaney banks against 161 / 196 chunks in all), padded with all-zero chunks to one
+// wave-uniform, even trip count:
+// mel_chunk[e * 20 + q] = chunk of bins | filter << 14 | (last chunk of its filter) << 21; its four weights are
+// mel_w[e][q][0..3] (for odd q with the halves swapped: the kernel reads the two halves of a power chunk in opposite order
+// there, to spread the banks).
 constexpr int CHUNK_LAST = 1 << 21;
 struct MelTables {      // device-resident, built once per plan
-    float window[NFFT];          // periodic Hann
+    float window[NFFT];          // periodic Hann / 2: the |X|^2 of the pair separation carries a factor 1/4
     float2 twiddle[NFFT];        // W400^(j*k1) stored at [k1*20 + j]
     int mel_chunk[MAX_CHUNKS * MEL_LANES];
-    float mel_w[MAX_NNZ];        // chunk 0 stays zero: the padding chunks point there
+    float mel_w[MAX_NNZ];        // [step][list][4]
 };
 
 // lane -> (pair, index in pair); lanes 60..63 shadow lanes 40..43
@@ -105,13 +112,13 @@ ASRK_HD void dft20(float (&re)[20], float (&im)[20]) {
 }
 
 // stage 1 of lane j: re / im hold the raw samples of the even / odd frame at n = 20 n1 + j on entry, the twiddled
-// column Y[k1][j] on exit.  `win` and `tw` are the tables (LDS on the device).
-ASRK_HD void fft400_stage1(float (&re)[20], float (&im)[20], const float* win, const float2* tw, int j) {
+// column Y[k1][j] on exit.  `win` = the lane's 20 window values window[20 n1 + j] (registers: the kernel is persistent);
+// `tw` = the twiddle table (LDS on the device).
+ASRK_HD void fft400_stage1(float (&re)[20], float (&im)[20], const float (&win)[20], const float2* tw, int j) {
 #pragma unroll
     for (int n1 = 0; n1 < 20; ++n1) {
-        const float w = win[20 * n1 + j];
-        re[n1] *= w;
-        im[n1] *= w;
+        re[n1] *= win[n1];
+        im[n1] *= win[n1];
     }
     dft20(re, im);
 #pragma unroll
@@ -128,6 +135,6 @@ ASRK_HD void fft400_stage1(float (&re)[20], float (&im)[20], const float* win, c
 ASRK_HD void fft400_power(float zr, float zi, float cr, float ci, float& p0, float& p1) {
     const float ar = zr + cr, ai = zi - ci;  // 2 * X_even[k]
     const float br = zr - cr, bi = zi + ci;  // 2i * X_odd[k]
-    p0 = 0.25f * (ar * ar + ai * ai);
-    p1 = 0.25f * (br * br + bi * bi);
+    p0 = ar * ar + ai * ai;  // the factor 1/4 is in the window (Hann / 2)
+    p1 = br * br + bi * bi;
 }

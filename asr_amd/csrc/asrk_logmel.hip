@@ -13,16 +13,17 @@
 //   both conflict-free; a wave's LDS operations execute in order, so there is NO workgroup barrier anywhere in the
 //   transform), a second 20-point DFT, and the separation of the two real spectra with the mirror bin fetched by a
 //   cross-lane ds_bpermute.  Samples come straight from global memory (each 20-lane group reads 80 contiguous bytes per
-//   instruction; the 60 % frame overlap is served by the vector cache), the window / twiddle / mel tables from LDS,
-//   loaded once per workgroup.  The power spectra of the wave's 6 frames go to the same private image, [frame][204];
-//   the mel projection reads them back by 16-byte chunks: lane = (frame, filters q, q + 10, ...) walks one flat,
-//   wave-uniform list of (4 bins x 4 weights) chunks of the sparse slaney bank, takes log10 at the end of each filter
-//   and puts the value into the tile's [n_mels][24] staging image.  The four waves meet only around that image (two
-//   barriers per tile).  The store pass (whole 96-byte row segments, per-wave maximum merged with one ordered-integer
-//   atomicMax) runs one tile late, behind the next tile's sample loads.
-//   36-41 KiB of LDS per workgroup and 82 VGPRs: 16 independent waves per CU, against 10 waves behind 5 barriers per
+//   instruction; the 60 % frame overlap is served by the vector cache), the window from registers (the workgroups are
+//   persistent), the twiddle / mel tables from LDS, loaded once per workgroup.  The power spectra go to the same private
+//   region, the two frames of a pair side by side, [pair][bin][2]; the mel projection reads them back by chunks of 4
+//   bins: lane = (frame pair, one of 20 equally long lists of filters) walks a flat, wave-uniform list of chunks
+//   (descriptor, 4 weights, 4 bins x 2 frames: 4 packed FMAs), takes log10 at the end of each filter and puts the two
+//   values into the tile's [n_mels][24] staging image.  The four waves meet only around that image (two barriers per
+//   tile).  The store pass (whole 96-byte row segments, (x + 4) / 4 applied, per-wave minimum for kernel 2, per-clip
+//   maximum in a register) runs one tile late, behind the next tile's sample loads.
+//   36-41 KiB of LDS per workgroup and ~100 VGPRs: 16 independent waves per CU, against 10 waves behind 5 barriers per
 //   tile in round 1's kernel (counter evidence: profiles/r2_logmel_*, history in DESIGN.md 4.1).
-// Kernel 2 (logmel_finish_kernel): applies max(x, clip_max - 8) and (x + 4) / 4 in place.
+// Kernel 2 (logmel_finish_kernel): the per-clip floor max(., clip_max - 8), in place, only where a tile needs it.
 #include "asrk_common.h"
 #include "asrk_fft400.h"
 #include "asrk_prof.h"
@@ -68,9 +69,8 @@ __device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
 
-// LDS carve-up (bytes): tables | staging [n_mels][24] | 4 wave-private images
-constexpr int OFF_WIN = 0;                                   // float[400]
-constexpr int OFF_TW = OFF_WIN + NFFT * 4;                   // float2[400]
+// LDS carve-up (bytes): tables | staging [n_mels][24] | 4 wave-private images (the window lives in registers)
+constexpr int OFF_TW = 0;                                    // float2[400]
 constexpr int OFF_MI = OFF_TW + NFFT * 8;                    // int[MAX_CHUNKS][MEL_LANES]
 constexpr int OFF_MW = OFF_MI + MAX_CHUNKS * MEL_LANES * 4;  // float[MAX_NNZ]
 constexpr int OFF_STAGE = OFF_MW + MAX_NNZ * 4;              // float[n_mels][TILE_F]
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
                                                                    unsigned* __restrict__ clip_max_key, float* __restrict__ tile_min,
                                                                    int n_chunks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Lwin = reinterpret_cast<float*>(smem + OFF_WIN);
     float2* Ltw = reinterpret_cast<float2*>(smem + OFF_TW);
     int* Lmi = reinterpret_cast<int*>(smem + OFF_MI);
     float* Lmw = reinterpret_cast<float*>(smem + OFF_MW);
@@ -107,15 +106,17 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
     float* priv = stage + n_mels * TILE_F + wv * PRIV_FLOATS;
 
     // ---- tables, once per workgroup
-    for (int i = tid; i < NFFT; i += NTHREADS) { Lwin[i] = tab->window[i]; Ltw[i] = tab->twiddle[i]; }
+    for (int i = tid; i < NFFT; i += NTHREADS) Ltw[i] = tab->twiddle[i];
     for (int i = tid; i < MAX_CHUNKS * MEL_LANES; i += NTHREADS) Lmi[i] = tab->mel_chunk[i];
     for (int i = tid; i < MAX_NNZ; i += NTHREADS) Lmw[i] = tab->mel_w[i];
     __syncthreads();
 
     const int g = lane_pair(lane), j = lane_j(lane);
     const int mir = mirror_lane(g, j) * 4;  // ds_bpermute byte address of the mirror lane
-    const int mf = lane / MEL_LANES, mq = lane % MEL_LANES;  // mel projection: frame in the wave (6 = idle lanes), mel mod 10
-    const bool mel_lane = lane < FPW * MEL_LANES;
+    const bool mel_lane = lane < PAIRS * MEL_LANES;  // mel projection: lane = (frame pair g, filter list j); 60..63 idle
+    float win[20];  // this lane's window values, for the life of the (persistent) workgroup
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) win[n1] = tab->window[20 * n1 + j];
 
 #ifdef ASRK_STAMPS
     unsigned long long lm_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
         prev_tile = tile;
         LSTAMP(7);  // store pass (of the previous tile)
         LSTAMP(0);  // sample loads (what is left exposed of them)
-        fft400_stage1(re, im, Lwin, Ltw, j);
+        fft400_stage1(re, im, win, Ltw, j);
         LSTAMP(1);  // window, DFT 1, twiddle
 
         // ---- 20 x 20 transpose inside the pair, real parts then imaginary parts through the same private image
@@ -276,64 +277,69 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
         dft20(zr, zi);  // Z[j + 20 k2] in register k2
         LSTAMP(3);  // DFT 2
 
-        // ---- separate the two real spectra; |X|^2 of bins 0..200 into the private image [frame][bin]
+        // ---- separate the two real spectra; |X|^2 of bins 0..200 into the private image [pair][bin][2 frames]
         {
-            float* p0 = priv + (2 * g) * PSTRIDE + j;
-            float* p1 = p0 + PSTRIDE;
+            float2* pp = reinterpret_cast<float2*>(priv + g * PPAIR) + j;
 #pragma unroll
             for (int k2 = 0; k2 < 10; ++k2) {
                 float cr = lane_fetch(mir, zr[mirror_reg(k2)]), ci = lane_fetch(mir, zi[mirror_reg(k2)]);
                 if (j == 0) { cr = zr[mirror_reg_lane0(k2)]; ci = zi[mirror_reg_lane0(k2)]; }
-                float a, b;
-                fft400_power(zr[k2], zi[k2], cr, ci, a, b);
-                p0[20 * k2] = a;
-                p1[20 * k2] = b;
+                float2 pw;
+                fft400_power(zr[k2], zi[k2], cr, ci, pw.x, pw.y);
+                pp[20 * k2] = pw;
             }
             if (j == 0) {  // bin 200: its mirror is itself
-                float a, b;
-                fft400_power(zr[10], zi[10], zr[mirror_reg_lane0(10)], zi[mirror_reg_lane0(10)], a, b);
-                p0[200] = a;
-                p1[200] = b;
-            } else if (j < 4) {  // bins 201..203 of the last 16-byte chunk: zeros (the exchange image leaves numbers there)
-                p0[200] = 0.f;
-                p1[200] = 0.f;
+                float2 pw;
+                fft400_power(zr[10], zi[10], zr[mirror_reg_lane0(10)], zi[mirror_reg_lane0(10)], pw.x, pw.y);
+                pp[200] = pw;
+            } else if (j < 4) {  // bins 201..203 of the last chunk: zeros (the exchange image leaves numbers there)
+                pp[200] = make_float2(0.f, 0.f);
             }
         }
         LSTAMP(4);  // mirror + power
         __syncthreads();  // every wave has stored the previous tile: the staging image is free (and orders the P image)
         LSTAMP(8);  // barrier: staging free
 
-        // ---- mel projection + log10: lane = (frame mf of the wave, filters mq, mq + 10, ...), one flat list of 16-byte
-        //      chunks (4 bins x 4 weights) per lane.  Four chunks at a time, all their loads first, so that one LDS round
-        //      trip serves 16 products (per-filter loops ran one dependent round trip per chunk: 17 k cycles per tile).
+        // ---- mel projection + log10: lane = (frame pair g, filter list j), one flat list of chunks (4 bins x 4 weights,
+        //      both frames of the pair) per lane.  Two chunks at a time, all their loads first, so that one LDS round trip
+        //      serves 16 products (per-filter loops ran one dependent round trip per chunk: 17 k cycles per tile).
         if (mel_lane) {
-            const char* prow = reinterpret_cast<const char*>(priv + mf * PSTRIDE);
+            const char* prow = reinterpret_cast<const char*>(priv + g * PPAIR);
             const char* wbase = reinterpret_cast<const char*>(Lmw);
-            char* srow = reinterpret_cast<char*>(stage + FPW * wv + mf);
-            const int* dq = Lmi + mq;
-            float acc = 0.f;
-            for (int e0 = 0; e0 < n_chunks; e0 += 4) {  // n_chunks: a multiple of 4, the same for every lane
-                int d[4];
-                float4 w[4], q[4];
+            char* srow = reinterpret_cast<char*>(stage + FPW * wv + 2 * g);
+            const int* dq = Lmi + j;
+            f32x2_t acc = f32x2_t{0.f, 0.f};
+            // Bank spreading: the weights lie [step][list], so the 20 lists read 320 consecutive bytes; the two 16-byte
+            // halves of a power chunk (bins 4c, 4c+1 | 4c+2, 4c+3) are read in opposite order by odd lists -- whose weight
+            // chunks are stored with their halves swapped to match -- so that each ds_read_b128 touches both halves of the
+            // 32-byte chunk grid and not only every other group of four banks.
+            const int hsw = (j & 1) << 4;
+            for (int e0 = 0; e0 < n_chunks; e0 += 2) {  // n_chunks: even, the same for every lane
+                int d[2];
+                float4 w[2], qa[2], qb[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) d[u] = dq[(e0 + u) * MEL_LANES];
+                for (int u = 0; u < 2; ++u) d[u] = dq[(e0 + u) * MEL_LANES];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    q[u] = *reinterpret_cast<const float4*>(prow + ((d[u] & 63) << 4));
-                    w[u] = *reinterpret_cast<const float4*>(wbase + (((d[u] >> 6) & 255) << 4));
+                for (int u = 0; u < 2; ++u) {
+                    const char* pc = prow + ((d[u] & 63) << 5);
+                    qa[u] = *reinterpret_cast<const float4*>(pc + hsw);         // even lists: bins 4c, 4c+1 x (even, odd frame)
+                    qb[u] = *reinterpret_cast<const float4*>(pc + (hsw ^ 16));  // even lists: bins 4c+2, 4c+3
+                    w[u] = *reinterpret_cast<const float4*>(wbase + ((e0 + u) * MEL_LANES + j) * 16);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc = fmaf(w[u].x, q[u].x, acc);
-                    acc = fmaf(w[u].y, q[u].y, acc);
-                    acc = fmaf(w[u].z, q[u].z, acc);
-                    acc = fmaf(w[u].w, q[u].w, acc);
+                for (int u = 0; u < 2; ++u) {
+                    acc += f32x2_t{qa[u].x, qa[u].y} * w[u].x;
+                    acc += f32x2_t{qa[u].z, qa[u].w} * w[u].y;
+                    acc += f32x2_t{qb[u].x, qb[u].y} * w[u].z;
+                    acc += f32x2_t{qb[u].z, qb[u].w} * w[u].w;
                     if (d[u] & CHUNK_LAST) {
                         // clamp(min=1e-10).log10(): silence is exactly -10.  v_log_f32 (log2, 1 ulp) * log10(2):
                         // |err| < 2e-6 here, against ~25 instructions for log10f()
-                        *reinterpret_cast<float*>(srow + ((d[u] >> 14) & 127) * (TILE_F * 4)) =
-                            acc > 1e-10f ? __builtin_amdgcn_logf(acc) * 0.30102999566398120f : -10.0f;
-                        acc = 0.f;
+                        float2 o;
+                        o.x = acc.x > 1e-10f ? __builtin_amdgcn_logf(acc.x) * 0.30102999566398120f : -10.0f;
+                        o.y = acc.y > 1e-10f ? __builtin_amdgcn_logf(acc.y) * 0.30102999566398120f : -10.0f;
+                        *reinterpret_cast<float2*>(srow + ((d[u] >> 14) & 127) * (TILE_F * 4)) = o;
+                        acc = f32x2_t{0.f, 0.f};
                     }
                 }
             }
@@ -415,7 +421,7 @@ struct asrk_logmel_plan {
     int n_mels;
     int device;
     int n_cus;
-    int n_chunks;               // chunks of 4 products per mel lane (a multiple of 4)
+    int n_chunks;               // chunks per mel lane (even)
     MelTables* tables;          // device
     unsigned* noalloc_scratch;  // this device's address of g_noalloc_clip_max
 };
@@ -425,34 +431,49 @@ extern "C" int asrk_logmel_plan_create(int n_mels, const float* mel_filters, asr
     if (n_mels < 1 || n_mels > MAX_MELS) return ASRK_ERR_SHAPE;
     MelTables* h = new MelTables();
     const double two_pi = 6.283185307179586476925286766559;
-    for (int n = 0; n < NFFT; ++n) h->window[n] = (float)(0.5 - 0.5 * cos(two_pi * n / NFFT));
+    for (int n = 0; n < NFFT; ++n) h->window[n] = (float)(0.5 * (0.5 - 0.5 * cos(two_pi * n / NFFT)));  // Hann / 2 (asrk_fft400.h)
     for (int k1 = 0; k1 < 20; ++k1)
         for (int n2 = 0; n2 < 20; ++n2) {
             const double a = -two_pi * (double)(n2 * k1) / NFFT;
             h->twiddle[k1 * 20 + n2] = make_float2((float)cos(a), (float)sin(a));
         }
-    // sparse rows of the bank cut into 16-byte chunks on the bin grid, and every mel lane's flat list of chunks
-    int nw = 4;  // chunk 0 of mel_w = zeros: the target of the padding chunks
-    for (int i = 0; i < MAX_NNZ; ++i) h->mel_w[i] = 0.f;
-    int per_lane[MEL_LANES] = {0};
-    for (int i = 0; i < MAX_CHUNKS * MEL_LANES; ++i) h->mel_chunk[i] = 0;  // padding chunk: bins 0..3 x zero weights, no output
+    // sparse rows of the bank cut into 16-byte chunks on the bin grid; the filters dealt to the MEL_LANES lists longest
+    // first onto the shortest list (asrk_fft400.h)
+    for (int i = 0; i < MAX_NNZ; ++i) h->mel_w[i] = 0.f;  // mel_w[step][list][4]; padding chunks keep zero weights
+    for (int i = 0; i < MAX_CHUNKS * MEL_LANES; ++i) h->mel_chunk[i] = 0;  // padding chunk: bins 0..3, no output
+    int flo[MAX_MELS], fnch[MAX_MELS], order[MAX_MELS];
     for (int m = 0; m < n_mels; ++m) {
         int lo = NBINS, hi = -1;
         for (int k = 0; k < NBINS; ++k)
             if (mel_filters[(size_t)k * n_mels + m] != 0.0f) { lo = k < lo ? k : lo; hi = k; }
         if (hi < 0) { lo = 0; hi = 0; }  // an empty filter: one chunk of zero weights, so that it still emits log10(1e-10)
-        const int c0 = lo / 4, nch = hi / 4 - c0 + 1, q = m % MEL_LANES;
-        if (nw + 4 * nch > MAX_NNZ || nw / 4 + nch > 256 || per_lane[q] + nch > MAX_CHUNKS) { delete h; return ASRK_ERR_SHAPE; }
-        for (int k = lo; k <= hi; ++k) h->mel_w[nw + k - 4 * c0] = mel_filters[(size_t)k * n_mels + m];
-        for (int c = 0; c < nch; ++c)
-            h->mel_chunk[(per_lane[q] + c) * MEL_LANES + q] =
-                (c0 + c) | ((nw / 4 + c) << 6) | (m << 14) | (c == nch - 1 ? CHUNK_LAST : 0);
+        flo[m] = lo / 4;
+        fnch[m] = hi / 4 - lo / 4 + 1;
+        order[m] = m;
+    }
+    for (int a = 1; a < n_mels; ++a)  // insertion sort by chunk count, descending, stable
+        for (int b = a; b > 0 && fnch[order[b]] > fnch[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    int per_lane[MEL_LANES] = {0};
+    for (int i = 0; i < n_mels; ++i) {
+        const int m = order[i], c0 = flo[m], nch = fnch[m];
+        int q = 0;
+        for (int l = 1; l < MEL_LANES; ++l)
+            if (per_lane[l] < per_lane[q]) q = l;
+        if (per_lane[q] + nch > MAX_CHUNKS) { delete h; return ASRK_ERR_SHAPE; }
+        for (int c = 0; c < nch; ++c) {
+            const int e = per_lane[q] + c;
+            h->mel_chunk[e * MEL_LANES + q] = (c0 + c) | (m << 14) | (c == nch - 1 ? CHUNK_LAST : 0);
+            for (int k = 0; k < 4; ++k) {
+                const int bin = 4 * (c0 + c) + k;
+                const float wv = bin < NBINS ? mel_filters[(size_t)bin * n_mels + m] : 0.f;
+                h->mel_w[(e * MEL_LANES + q) * 4 + ((q & 1) ? (k ^ 2) : k)] = wv;  // odd lists: halves swapped (kernel)
+            }
+        }
         per_lane[q] += nch;
-        nw += 4 * nch;
     }
     int n_chunks = 0;
     for (int q = 0; q < MEL_LANES; ++q) n_chunks = per_lane[q] > n_chunks ? per_lane[q] : n_chunks;
-    n_chunks = (n_chunks + 3) / 4 * 4;
+    n_chunks = (n_chunks + 1) / 2 * 2;
     if (n_chunks > MAX_CHUNKS) { delete h; return ASRK_ERR_SHAPE; }
     asrk_logmel_plan* p = new asrk_logmel_plan();
     p->n_mels = n_mels;

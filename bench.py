@@ -246,7 +246,9 @@ PROF_FLOPS = (0, 5, 6, 1)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 10; 100 for the sub-millisecond workloads logmel / logmel-128 / splice, whose "
+                         "timed region would otherwise be dominated by its two synchronisations)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pipeline-small", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: the workload's)")
@@ -257,6 +259,8 @@ def main():
                          "stream; prefetch / prefetch16: asr_amd.collate.FeaturePrefetcher (fp32 / int16 ragged buffer, copy "
                          "on a side stream, pad + mask on the GPU)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 100 if (args.workload.startswith("logmel") or args.workload == "splice") else 10
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))

@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
     fclose(f);
     MelTables* tab = new MelTables();
     const double two_pi = 6.283185307179586476925286766559;
-    for (int n = 0; n < NFFT; ++n) tab->window[n] = (float)(0.5 - 0.5 * cos(two_pi * n / NFFT));
+    for (int n = 0; n < NFFT; ++n) tab->window[n] = (float)(0.5 * (0.5 - 0.5 * cos(two_pi * n / NFFT)));  // Hann / 2
     for (int k1 = 0; k1 < 20; ++k1)
         for (int n2 = 0; n2 < 20; ++n2) {
             const double a = -two_pi * (double)(n2 * k1) / NFFT;
@@ -34,7 +34,9 @@ int main(int argc, char** argv) {
             re[lane][n1] = S[(2 * g) * HOP + 20 * n1 + j];
             im[lane][n1] = S[(2 * g + 1) * HOP + 20 * n1 + j];
         }
-        fft400_stage1(re[lane], im[lane], tab->window, tab->twiddle, j);
+        float win[20];
+        for (int n1 = 0; n1 < 20; ++n1) win[n1] = tab->window[20 * n1 + j];
+        fft400_stage1(re[lane], im[lane], win, tab->twiddle, j);
     }
     // exchange: all lanes write, then all lanes read their row -- first the real parts, then the imaginary parts
     for (int pass = 0; pass < 2; ++pass) {
@@ -47,7 +49,7 @@ int main(int argc, char** argv) {
     }
     for (int lane = 0; lane < 64; ++lane) dft20(zr[lane], zi[lane]);
     // mirror fetch + power image [frame][bin] in the same private region
-    std::vector<float> P(FPW * PSTRIDE, -1.0f);
+    std::vector<float> P(FPW * PBINS, -1.0f);
     for (int lane = 0; lane < 64; ++lane) {
         const int g = lane_pair(lane), j = lane_j(lane), ml = mirror_lane(g, j);
         for (int k2 = 0; k2 <= 10; ++k2) {
@@ -55,8 +57,8 @@ int main(int argc, char** argv) {
             float cr, ci;
             if (j == 0) { cr = zr[lane][mirror_reg_lane0(k2)]; ci = zi[lane][mirror_reg_lane0(k2)]; }
             else { cr = zr[ml][mirror_reg(k2)]; ci = zi[ml][mirror_reg(k2)]; }
-            fft400_power(zr[lane][k2], zi[lane][k2], cr, ci, P[(2 * g) * PSTRIDE + j + 20 * k2],
-                         P[(2 * g + 1) * PSTRIDE + j + 20 * k2]);
+            fft400_power(zr[lane][k2], zi[lane][k2], cr, ci, P[(2 * g) * PBINS + j + 20 * k2],
+                         P[(2 * g + 1) * PBINS + j + 20 * k2]);
         }
     }
     f = fopen(argv[2], "wb");

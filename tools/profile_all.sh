@@ -10,7 +10,7 @@ for wl in $WLS; do
   O=$R/gpurun_out/profall/$wl
   rm -rf $O && mkdir -p $O
   echo "== $wl"
-  timeout -k 10 400 python $R/bench.py --workload $wl --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
+  timeout -k 10 400 python $R/bench.py --workload $wl --warmup 3 > $O/bench.json 2> $O/bench.err
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err
   if [ $wl = pipeline-small ]; then
     timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python $R/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_f.json 2> $O/pmc_f.err
