@@ -4,7 +4,16 @@
 #include "asrk_gemm.h"
 #include "asrk_prof.h"
 
+// Which multiply-adds fuse is written out (fmaf) and the compiler's own contraction is off for this file: the same row
+// must come out bit-identical from every instantiation (generic / width-specialised LayerNorm, the LayerNorm + RMSNorm
+// kernel against the two separate ones) -- tests compare them with torch.equal.
+#pragma clang fp contract(off)
+
 namespace {
+
+__device__ __forceinline__ float sumsq4(float a0, float a1, float a2, float a3) {
+    return fmaf(a0, a0, a1 * a1) + fmaf(a2, a2, a3 * a3);
+}
 
 constexpr int MAX_V4 = 8;  // per-lane float4 chunks: D <= 64 * 4 * 8 = 2048
 
@@ -13,21 +22,25 @@ constexpr int MAX_V4 = 8;  // per-lane float4 chunks: D <= 64 * 4 * 8 = 2048
 // included; HF modeling_whisper.py:399,407), and the updated fp32 row is written back unless this is the
 // encoder's last norm (KEEP_X false).  The fp32 read-modify-write of the residual stream thereby runs in this
 // streaming kernel at >5 TB/s instead of in a GEMM epilogue, where every CU waits on it at once.
-template <bool OUT_BF16, bool ADD, bool KEEP_X>
+// NV: float4 chunks per lane when D == 256 NV exactly (768 -> 3, 1280 -> 5: the encoder widths; no per-chunk bounds
+// test, no dead iterations -- at D = 1280 the generic form ran at 0.71 of the HBM peak against 0.81 at D = 768), or 0
+// for any D % 4 == 0 up to 2048.
+template <bool OUT_BF16, bool ADD, bool KEEP_X, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* x, const bf16_t* __restrict__ delta,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         void* __restrict__ out, int M, int D, float eps) {
+    constexpr int NI = NV ? NV : MAX_V4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const int nv = D >> 2;  // float4 per row
+    const int nv = NV ? 64 * NV : D >> 2;  // float4 per row
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
-    float4 v[MAX_V4];
+    float4 v[NI];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_V4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
-        if (c < nv) {
+        if (NV || c < nv) {
             if (ADD) {
                 // the fp32 residual stream and the delta are touched once per layer step: non-temporal, so that what
                 // stays in the memory-side cache is the bf16 output the next GEMM reads
@@ -45,25 +58,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* x, const bf16_t* 
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_V4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
-        if (c < nv) {
+        if (NV || c < nv) {
             const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            q += sumsq4(a0, a1, a2, a3);
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < MAX_V4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
-        if (c < nv) {
+        if (NV || c < nv) {
             const float4 ww = reinterpret_cast<const float4*>(w)[c];
             const float4 bb = reinterpret_cast<const float4*>(b)[c];
             float4 o;
-            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
-            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
-            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
-            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            o.x = fmaf((v[i].x - mean) * rstd, ww.x, bb.x);
+            o.y = fmaf((v[i].y - mean) * rstd, ww.y, bb.y);
+            o.z = fmaf((v[i].z - mean) * rstd, ww.z, bb.z);
+            o.w = fmaf((v[i].w - mean) * rstd, ww.w, bb.w);
             if (OUT_BF16) {
                 bf16x4 p;
                 p[0] = (bf16_t)o.x; p[1] = (bf16_t)o.y; p[2] = (bf16_t)o.z; p[3] = (bf16_t)o.w;
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         const int c = lane + 64 * i;
         if (c < nv) {
             v[i] = xr[c];
-            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            q += sumsq4(v[i].x, v[i].y, v[i].z, v[i].w);
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_rms_kernel(const float* __restr
         const int c = lane + 64 * i;
         if (c < nv) {
             const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            q += sumsq4(a0, a1, a2, a3);
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
@@ -162,13 +175,13 @@ __global__ __launch_bounds__(256) void layernorm_rms_kernel(const float* __restr
             const float4 ww = reinterpret_cast<const float4*>(w)[c];
             const float4 bb = reinterpret_cast<const float4*>(b)[c];
             float4 o;
-            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
-            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
-            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
-            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            o.x = fmaf((v[i].x - mean) * rstd, ww.x, bb.x);
+            o.y = fmaf((v[i].y - mean) * rstd, ww.y, bb.y);
+            o.z = fmaf((v[i].z - mean) * rstd, ww.z, bb.z);
+            o.w = fmaf((v[i].w - mean) * rstd, ww.w, bb.w);
             if (y_out) reinterpret_cast<float4*>(y_out + (size_t)row * D)[c] = o;
             v[i] = o;
-            q2 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+            q2 += sumsq4(o.x, o.y, o.z, o.w);
         }
     }
     const float rstd2 = rsqrtf(wave_sum(q2) / (float)D + rms_eps);
@@ -199,6 +212,17 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     }
 }
 
+template <bool OUT_BF16, bool ADD, bool KEEP_X>
+void launch_ln(dim3 grid, hipStream_t st, float* x, const bf16_t* delta, const float* w, const float* b, void* out, int M, int D,
+               float eps) {
+    if (D == 768)
+        hipLaunchKernelGGL((layernorm_kernel<OUT_BF16, ADD, KEEP_X, 3>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+    else if (D == 1280)
+        hipLaunchKernelGGL((layernorm_kernel<OUT_BF16, ADD, KEEP_X, 5>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<OUT_BF16, ADD, KEEP_X, 0>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+}
+
 }  // namespace
 
 int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* out, bool out_bf16, int M, int D,
@@ -210,9 +234,9 @@ int asrk_launch_layernorm(const float* x, const float* w, const float* b, void* 
     AsrkProfScope prof(ASRK_PROF_NORM, (double)M * D * (out_bf16 ? 6.0 : 8.0), st);
     float* xm = const_cast<float*>(x);  // the plain variant never writes x
     if (out_bf16)
-        hipLaunchKernelGGL((layernorm_kernel<true, false, false>), grid, dim3(256), 0, st, xm, nullptr, w, b, out, M, D, eps);
+        launch_ln<true, false, false>(grid, st, xm, nullptr, w, b, out, M, D, eps);
     else
-        hipLaunchKernelGGL((layernorm_kernel<false, false, false>), grid, dim3(256), 0, st, xm, nullptr, w, b, out, M, D, eps);
+        launch_ln<false, false, false>(grid, st, xm, nullptr, w, b, out, M, D, eps);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
 
@@ -227,13 +251,13 @@ int asrk_launch_add_layernorm(float* x, const bf16_t* delta, const float* w, con
     // algorithmic bytes per element: x read 4 + delta read 2 + x write 4 (if kept) + output 2 or 4
     AsrkProfScope prof(ASRK_PROF_NORM, (double)M * D * (6.0 + (keep_x ? 4.0 : 0.0) + (out_bf16 ? 2.0 : 4.0)), st);
     if (out_bf16 && keep_x)
-        hipLaunchKernelGGL((layernorm_kernel<true, true, true>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+        launch_ln<true, true, true>(grid, st, x, delta, w, b, out, M, D, eps);
     else if (out_bf16)
-        hipLaunchKernelGGL((layernorm_kernel<true, true, false>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+        launch_ln<true, true, false>(grid, st, x, delta, w, b, out, M, D, eps);
     else if (keep_x)
-        hipLaunchKernelGGL((layernorm_kernel<false, true, true>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+        launch_ln<false, true, true>(grid, st, x, delta, w, b, out, M, D, eps);
     else
-        hipLaunchKernelGGL((layernorm_kernel<false, true, false>), grid, dim3(256), 0, st, x, delta, w, b, out, M, D, eps);
+        launch_ln<false, true, false>(grid, st, x, delta, w, b, out, M, D, eps);
     return hipGetLastError() == hipSuccess ? ASRK_OK : ASRK_ERR_HIP;
 }
 

@@ -4,7 +4,7 @@
 set -e -o pipefail
 for l in "$@"; do
   export ASRK_LIB_PATH=$PWD/asr_amd/lib$l.so
-  timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_$l.json
+  timeout -k 10 200 python bench.py --workload ${WL:-pipeline-small} --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_$l.json
   python - "$l" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
