@@ -175,7 +175,7 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& a, f32x4 (&acc)[4][8
 // 2 workgroups / CU so that one's epilogue overlaps the other's K loop).
 template <int WN, int BK, int NSTAGE, bool GELU, bool OUT_BF16>
 __global__ __launch_bounds__(128 * WN, 2) void gemm256_kernel(const GemmArgs a) {
-    constexpr int NTHR = 128 * WN, NW = 2 * WN, BN = 64 * WN;
+    constexpr int NTHR = 128 * WN, BN = 64 * WN;
     constexpr int RB = BK * 2;              // bytes per LDS row
     constexpr int CPR = RB / 16;            // 16-byte chunks per row (8 or 4)
     constexpr int XOPER = 256 * RB;         // bytes of the X slice per stage
