@@ -67,6 +67,30 @@ __device__ __forceinline__ f32x2_t gelu_erf_x2(f32x2_t x) {
     return __builtin_elementwise_fma(ax, w, x);              // x + |x| erf(|x| / sqrt 2) = 2 gelu(x)
 }
 
+// 2 * gelu(x) for the GEMM epilogues, two values at a time, in the logistic form gelu(x) = x * sigma(x q(x^2)) with a
+// quadratic q fitted (minimax over |x| <= 7.25, where sigma has saturated to 1 - 7e-12) to the exact erf GELU:
+// |err| <= 2.6e-5 absolute, evaluated in fp32 -- on N(0, 1.5^2) pre-activations rounded to bf16 the relative L2
+// distance from the exact function is the rounding's own 1.6555e-3 to five digits.  6 packed + 2 plain + 4 transcendental
+// issues per pair = 32 cycles per value against 42 for gelu_erf_x2 (11 + 2 + 4): the GELU epilogue of fc1 is bound by
+// exactly this count.  The coefficients carry -log2(e), so the exponential is a bare v_exp_f32.
+__device__ __forceinline__ f32x2_t gelu2_x2(f32x2_t x) {
+    f32x2_t xc;
+    xc.x = __builtin_amdgcn_fmed3f(x.x, -7.25f, 7.25f);
+    xc.y = __builtin_amdgcn_fmed3f(x.y, -7.25f, 7.25f);
+    const f32x2_t s = xc * xc;
+    f32x2_t q = __builtin_elementwise_fma(s, f32x2_t{0.001014263f, 0.001014263f}, f32x2_t{-0.10677572f, -0.10677572f});
+    q = __builtin_elementwise_fma(s, q, f32x2_t{-2.3011212f, -2.3011212f});
+    const f32x2_t t = q * xc;  // -log2(e) x q(x^2)
+    f32x2_t e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2_t d = __builtin_elementwise_fma(e, f32x2_t{0.5f, 0.5f}, f32x2_t{0.5f, 0.5f});  // (1 + e) / 2
+    f32x2_t r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return x * r;  // 2 x sigma(.)
+}
+
 // d/dx of the exact GELU: Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

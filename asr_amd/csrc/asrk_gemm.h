@@ -36,12 +36,18 @@ bool asrk_gemm256p_fits(const GemmArgs& a);  // operands within the persistent k
 // Element part of the epilogue (everything except residual and store) for 4 consecutive n of row m.
 // `bv` is the bias of those 4 columns, loaded once by the caller (it does not depend on the row: a load
 // per accumulator made the epilogue a chain of 32 dependent L2 round trips, 9.8 k cycles per tile).
-template <bool GELU>
+// 2 gelu of two values: the logistic form where the result is rounded to bf16 anyway (every bf16-output path uses the
+// same one, so a clip's features do not depend on which tile kernel its batch size selects), the erf form (|err| <= 5e-7)
+// for fp32 outputs (conv2 -> residual stream)
+template <bool OUT_BF16>
+__device__ __forceinline__ f32x2_t gemm_gelu2(f32x2_t x) { return OUT_BF16 ? gelu2_x2(x) : gelu_erf_x2(x); }
+
+template <bool GELU, bool OUT_BF16>
 __device__ __forceinline__ f32x4 gemm_epilogue_value(float alpha, const bf16_t* dg_pre, int64_t ld_dg, bool in_range, f32x4 v,
                                                      f32x4 bv, int m, int n) {
     v += bv;
     if (GELU) {
-        const f32x2_t lo = gelu_erf_x2(f32x2_t{v[0], v[1]}), hi = gelu_erf_x2(f32x2_t{v[2], v[3]});
+        const f32x2_t lo = gemm_gelu2<OUT_BF16>(f32x2_t{v[0], v[1]}), hi = gemm_gelu2<OUT_BF16>(f32x2_t{v[2], v[3]});
         v = f32x4{lo.x, lo.y, hi.x, hi.y} * (0.5f * alpha);
     } else {
         v *= alpha;
@@ -56,9 +62,9 @@ __device__ __forceinline__ f32x4 gemm_epilogue_value(float alpha, const bf16_t* 
 // The same from the argument block.  Kernels whose epilogue is unrolled should read alpha / dg_pre / ld_dg into
 // locals once and call the form above: through the reference the compiler re-reads them from a scratch copy of
 // the kernel arguments at every call (32 scratch loads, each behind an s_waitcnt vmcnt(0), per 256 x 256 tile).
-template <bool GELU>
+template <bool GELU, bool OUT_BF16>
 __device__ __forceinline__ f32x4 gemm_epilogue_value(const GemmArgs& a, f32x4 v, f32x4 bv, int m, int n) {
-    return gemm_epilogue_value<GELU>(a.alpha, a.dg_pre, a.ld_dg, m < a.M && n < a.N, v, bv, m, n);
+    return gemm_epilogue_value<GELU, OUT_BF16>(a.alpha, a.dg_pre, a.ld_dg, m < a.M && n < a.N, v, bv, m, n);
 }
 
 // Shared epilogue: v = 4 consecutive n (n .. n+3) of output row m.  `orow` is the element offset
@@ -68,7 +74,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& a, f32x4 v, 
                                                     const float* rrow) {
     v += bv;
     if (GELU) {
-        const f32x2_t lo = gelu_erf_x2(f32x2_t{v[0], v[1]}), hi = gelu_erf_x2(f32x2_t{v[2], v[3]});
+        const f32x2_t lo = gemm_gelu2<OUT_BF16>(f32x2_t{v[0], v[1]}), hi = gemm_gelu2<OUT_BF16>(f32x2_t{v[2], v[3]});
         v = f32x4{lo.x, lo.y, hi.x, hi.y} * (0.5f * a.alpha);
     } else {
         v *= a.alpha;

@@ -76,7 +76,7 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& a, f32x4 (&acc)[4][8
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int nl = wn * 64 + nt * 16 + fq * 4;
-                const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + ml, n0 + nl);
+                const f32x4 v = gemm_epilogue_value<GELU, OUT_BF16>(a, acc[nt][mt], bv[nt], m0 + ml, n0 + nl);
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
@@ -140,7 +140,7 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& a, f32x4 (&acc)[4][8
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const int nl = wn * 64 + nt * 16 + fq * 4;
-                        const f32x4 v = gemm_epilogue_value<GELU>(a, acc[nt][mt], bv[nt], m0 + half * 128 + ml, n0 + nl);
+                        const f32x4 v = gemm_epilogue_value<GELU, OUT_BF16>(a, acc[nt][mt], bv[nt], m0 + half * 128 + ml, n0 + nl);
                         *reinterpret_cast<f32x4*>(smem + ml * EP_ROW_F32 + nl * 4) = v;
                     }
                 }

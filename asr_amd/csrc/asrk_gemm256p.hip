@@ -134,7 +134,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
                 for (int nt = 0; nt < 4; ++nt) {
                     f32x4 v = acc[nt][mt] + bv[nt];
                     if (GELU) {
-                        const f32x2_t lo = gelu_erf_x2(f32x2_t{v[0], v[1]}), hi = gelu_erf_x2(f32x2_t{v[2], v[3]});
+                        const f32x2_t lo = gelu2_x2(f32x2_t{v[0], v[1]}), hi = gelu2_x2(f32x2_t{v[2], v[3]});
                         v = f32x4{lo.x, lo.y, hi.x, hi.y} * (0.5f * alpha);
                     } else {
                         v *= alpha;
@@ -184,7 +184,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int m = mw + mt * 16 + frow, n = nw + nt * 16 + fq * 4;
-                const f32x4 v = gemm_epilogue_value<GELU>(alpha, dg_pre, ld_dg, m < M && n < N, acc[nt][mt], bv[nt], m, n);
+                const f32x4 v = gemm_epilogue_value<GELU, true>(alpha, dg_pre, ld_dg, m < M && n < N, acc[nt][mt], bv[nt], m, n);
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
@@ -235,7 +235,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, f32x4 (&acc)[4]
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int m = mw + mt * 16 + frow, n = nw + nt * 16 + fq * 4;
-                const f32x4 v = gemm_epilogue_value<GELU>(alpha, dg_pre, ld_dg, m < M && n < N, acc[nt][mt], bv[nt], m, n);
+                const f32x4 v = gemm_epilogue_value<GELU, false>(alpha, dg_pre, ld_dg, m < M && n < N, acc[nt][mt], bv[nt], m, n);
                 *reinterpret_cast<f32x4*>(patch + frow * 256 + (((nt * 4 + fq) ^ frow) << 4)) = v;
             }
             wave_lds_order();

@@ -95,7 +95,8 @@ def test_production_gemm_shapes_bit_exact(lib, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(96000, 3072, 768), (24000, 5120, 1280)])
 def test_production_fc1_gelu_shape(lib, M, N, K):
     """fc1 with the fused GELU epilogue (gemm256p_kernel<8, 1, true>) at its production shapes: the pre-activations
-    are exact integers, so out must be gelu(float64) rounded once to bf16 (the packed erf evaluation is within 5e-7)."""
+    are exact integers, so out must be gelu(float64) rounded once to bf16, plus the 2.6e-5 absolute bound of the epilogue's
+    logistic-form evaluation (asrk_common.h: gelu2_x2)."""
     x, w, bias = _int_operands(M, N, K, seed=11 + M + N)
     bias = bias * 0.25  # quarter-integer pre-activations: exercises the erf between the integers too (still exact in fp32)
     out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
@@ -107,7 +108,7 @@ def test_production_fc1_gelu_shape(lib, M, N, K):
         pre = pre.double()
         ref = 0.5 * pre * (1.0 + torch.erf(pre / np.sqrt(2.0)))
         err = (out[r0:r0 + pre.shape[0]].double() - ref).abs()
-        bound = ref.abs() * 2.0 ** -8 + 4e-6
+        bound = ref.abs() * 2.0 ** -8 + 3e-5
         assert bool((err <= bound).all()), f"rows {r0}..: max excess {(err - bound).max().item():.3e}"
         worst = max(worst, err.max().item())
     print(f"fc1+GELU M={M} N={N} K={K}: max abs err {worst:.3e}")

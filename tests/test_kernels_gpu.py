@@ -98,9 +98,10 @@ def test_gemm_large_tiles_exact(lib, M, N, K, out_bf16):
 
 @pytest.mark.parametrize("M,out_bf16", [(4096, False), (70000, True)])
 def test_gemm_gelu_epilogue_accuracy(lib, M, out_bf16):
-    """W = I, so out = alpha * gelu(x + bias) element by element: the packed-fp32 erf GELU of the epilogues against
-    float64 erf.  fp32 output (128-tile and one-tile 256 kernels): |err| <= 1e-6 * max(1, |x|); bf16 output at a size
-    that takes the persistent kernel's straight-line epilogue: exact to bf16 rounding."""
+    """W = I, so out = alpha * gelu(x + bias) element by element, against float64 erf.  fp32 output (128-tile and
+    one-tile 256 kernels; the packed-fp32 erf form): |err| <= 1e-6 * max(1, |x|); bf16 output at a size that takes the
+    persistent kernel's straight-line epilogue (the logistic form, |err| <= 2.6e-5 before the rounding): one bf16
+    rounding plus that bound.  Inputs reach +-40, far beyond the fit's clamp at 7.25."""
     K = N = 256
     g = torch.Generator(device="cuda").manual_seed(M)
     x = (torch.rand((M, K), device="cuda", generator=g) * 24.0 - 12.0).to(torch.bfloat16)
@@ -116,9 +117,9 @@ def test_gemm_gelu_epilogue_accuracy(lib, M, out_bf16):
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     if out_bf16:
-        # fp32 value within 2e-6 of the truth, then one bf16 rounding (relative 2^-9 incl. ties)
+        # fp32 value within alpha * 2.6e-5 of the truth, then one bf16 rounding (relative 2^-9 incl. ties)
         err = (out.double() - ref).abs()
-        assert (err <= ref.abs() * 2.0 ** -8 + 4e-6).all(), err.max().item()
+        assert (err <= ref.abs() * 2.0 ** -8 + 3.5e-5).all(), err.max().item()
     else:
         err = (out.double() - ref).abs() / pre.abs().clamp(min=1.0)
         assert err.max().item() <= 1.5e-6, err.max().item()
