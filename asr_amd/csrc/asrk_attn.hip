@@ -72,36 +72,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int srow = tid >> 3;  // + 32 * i
     const int slot = tid & 7;
     const int wave_lds = wave * 1024;
-    // source pointers of this thread's chunks in key tile 0; a tile further on is KT rows (tile_step elements) away.
-    // Only the ragged last tile needs its rows clamped, so only that one recomputes them.
-    const bf16_t* kp[2];
-    const bf16_t* vp[2];
+    // Sources of this thread's chunks: 32-bit byte offsets from the (workgroup-uniform) start of key tile kt, so that
+    // the DMA takes a scalar base + one offset register per chunk and no 64-bit lane arithmetic runs per tile.  The
+    // ragged last tile clamps its rows (to the clip's last key) and recomputes its offsets, once per workgroup.
+    const int ldb = 3 * d * 2;  // bytes per row of qkv
+    uint32_t ko[2], vo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = srow + 32 * i;
-        const bf16_t* rp = base + (int64_t)(row < T ? row : T - 1) * ld;
-        kp[i] = rp + d + (slot ^ ((row >> 1) & 7)) * 8;            // K image: chunk ^ ((row >> 1) & 7)
-        vp[i] = rp + 2 * d + (slot ^ (((row >> 1) & 1) << 2)) * 8;  // V image: chunk ^ (((row >> 1) & 1) << 2)
+        ko[i] = (uint32_t)(row * ldb + (d + (slot ^ ((row >> 1) & 7)) * 8) * 2);            // K image: chunk ^ ((row >> 1) & 7)
+        vo[i] = (uint32_t)(row * ldb + (2 * d + (slot ^ (((row >> 1) & 1) << 2)) * 8) * 2);  // V image: chunk ^ (((row >> 1) & 1) << 2)
     }
-    const int64_t tile_step = (int64_t)KT * ld;
+    const int64_t tile_step = (int64_t)KT * ldb;  // bytes
     auto stage = [&](int kt, int buf) {
         char* kb = smem + buf * (2 * TILE_B);
         char* vb = kb + TILE_B;
+        const char* tb = uniform_ptr(reinterpret_cast<const char*>(base) + kt * tile_step);
         if ((kt + 1) * KT <= T) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                glds16(kp[i] + kt * tile_step, kb + i * 4096 + wave_lds);
-                glds16(vp[i] + kt * tile_step, vb + i * 4096 + wave_lds);
+                glds16(tb + ko[i], kb + i * 4096 + wave_lds);
+                glds16(tb + vo[i], vb + i * 4096 + wave_lds);
             }
         } else {
+            const int last = T - 1 - kt * KT;  // last valid row of this tile
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = srow + 32 * i;
-                int kv = kt * KT + row;
-                kv = kv < T ? kv : T - 1;
-                const bf16_t* rp = base + (int64_t)kv * ld;
-                glds16(rp + d + (slot ^ ((row >> 1) & 7)) * 8, kb + i * 4096 + wave_lds);
-                glds16(rp + 2 * d + (slot ^ (((row >> 1) & 1) << 2)) * 8, vb + i * 4096 + wave_lds);
+                const uint32_t back = (uint32_t)((row > last ? row - last : 0) * ldb);  // rows past the end read the last key
+                glds16(tb + (ko[i] - back), kb + i * 4096 + wave_lds);
+                glds16(tb + (vo[i] - back), vb + i * 4096 + wave_lds);
             }
         }
     };
