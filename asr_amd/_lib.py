@@ -56,7 +56,7 @@ _SIGNATURES = {
     "asrk_logmel_plan_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
     "asrk_logmel_plan_destroy": (None, [c_void_p]),
     "asrk_logmel_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "asrk_logmel_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "asrk_logmel_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "asrk_logmel_f32_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "asrk_encoder_create": (c_int, [POINTER(EncoderDims), POINTER(EncoderWeights), c_void_p, POINTER(c_void_p)]),
     "asrk_encoder_destroy": (None, [c_void_p]),

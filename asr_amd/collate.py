@@ -63,6 +63,11 @@ def collate_on_device(pcm: torch.Tensor, offsets: torch.Tensor, target: int, hop
     return wave, mask
 
 
+def _valid_lengths(offsets: torch.Tensor, target: int) -> torch.Tensor:
+    """Samples of each clip in front of the zero padding asrk_collate_pcm writes (clips are truncated to `target`)."""
+    return (offsets[1:] - offsets[:-1]).clamp(max=target).to(torch.int32)
+
+
 def device_collate(fe: LogMelFeatureExtractor, clips: Sequence, dtype=np.float32, max_length: Optional[int] = None,
                    device=None) -> BatchFeature:
     """Same result as ``fe(clips, padding="max_length", max_length=..., return_attention_mask=True)``."""
@@ -70,9 +75,9 @@ def device_collate(fe: LogMelFeatureExtractor, clips: Sequence, dtype=np.float32
     pcm, offsets = pack_ragged(clips, dtype)
     target = max_length if max_length else fe.n_samples
     with torch.cuda.device(dev):
-        wave, mask = collate_on_device(pcm.to(dev, non_blocking=True), offsets.to(dev, non_blocking=True), target,
-                                       fe.hop_length)
-        feats = fe.extract_from_device(wave)
+        d_off = offsets.to(dev, non_blocking=True)
+        wave, mask = collate_on_device(pcm.to(dev, non_blocking=True), d_off, target, fe.hop_length)
+        feats = fe.extract_from_device(wave, _valid_lengths(d_off, target))
     return BatchFeature(input_features=feats, attention_mask=mask)
 
 
@@ -119,5 +124,5 @@ class FeaturePrefetcher:
         d_off.record_stream(cur)
         with torch.cuda.device(self.dev):
             wave, mask = collate_on_device(d_pcm, d_off, self.target, self.fe.hop_length)
-            feats = self.fe.extract_from_device(wave)
+            feats = self.fe.extract_from_device(wave, _valid_lengths(d_off, self.target))
         return BatchFeature(input_features=feats, attention_mask=mask)

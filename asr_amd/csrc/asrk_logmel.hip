@@ -23,7 +23,10 @@
 //   maximum in a register) runs one tile late, behind the next tile's sample loads.
 //   36-41 KiB of LDS per workgroup and ~100 VGPRs: 16 independent waves per CU, against 10 waves behind 5 barriers per
 //   tile in round 1's kernel (counter evidence: profiles/r2_logmel_*, history in DESIGN.md 4.1).
-// Kernel 2 (logmel_finish_kernel): the per-clip floor max(., clip_max - 8), in place, only where a tile needs it.
+//   With the clips' valid lengths (optional) a tile that lies entirely in zero padding is written as silence without
+//   being loaded or transformed.
+// Kernel 2 (logmel_finish_kernel): the per-clip floor max(., clip_max - 8), in place, only where a tile needs it (and
+//   write-only where the tiles were skipped as padding).
 #include "asrk_common.h"
 #include "asrk_fft400.h"
 #include "asrk_prof.h"
@@ -81,8 +84,30 @@ constexpr size_t tile_lds_bytes(int n_mels) {
 static_assert(tile_lds_bytes(MAX_MELS) <= 163840 / 4, "four workgroups per CU");
 
 constexpr int LOGMEL_WPS = 4;  // workgroups per CU (= waves per SIMD)
+constexpr int TGROUP = 4;      // neighbouring tiles of a clip dealt to neighbouring workgroups
+
+// Work item -> (clip, tile of the clip).  Row r = item / (4 n_clips) holds tile group r of every clip, four neighbouring
+// tiles of a clip side by side (they share their overlapping samples and complete each other's 128-byte output lines in
+// L2), the clips rotated by 61 r so that a workgroup meets a different clip in every round.
+__device__ __forceinline__ int item_clip_of(int item, int n_clips) {
+    const int per_row = TGROUP * n_clips, r = item / per_row;
+    return ((item - r * per_row) / TGROUP + 61 * r) % n_clips;
+}
+__device__ __forceinline__ int item_tile_of(int item, int n_clips) {  // may be >= tiles_per_clip (padding item)
+    return (item / (TGROUP * n_clips)) * TGROUP + item % TGROUP;
+}
+// A tile lies entirely in a clip's zero padding when the smallest sample index any of its frames touches -- reflection
+// at either end of the clip included -- is at or after the clip's valid length.
+__device__ __forceinline__ bool tile_is_padding(int tile_of_clip, int valid, int n_samples) {
+    const int s0 = tile_of_clip * TILE_F * HOP - NFFT / 2, s1 = s0 + (TILE_F - 1) * HOP + NFFT - 1;
+    int lo = s0 > 0 ? s0 : 0;
+    if (s1 >= n_samples) lo = min(lo, max(2 * (n_samples - 1) - s1, 0));
+    return valid <= lo;
+}
+
 constexpr int KEY_STRIDE = 32;  // words between the per-clip maximum keys: one 128-byte line each (see store_tile)
 constexpr int FIN_TILES = 4;    // tiles per workgroup of the finish kernel
+
 // ROW_ITERS = ceil(n_mels / 42): the store pass is unrolled by it, so that the number of global stores per tile is known
 // at compile time.  A wave's vector-memory operations complete in issue order and the next tile's sample loads are
 // issued BEFORE this tile's stores; with a countable number of stores the compiler waits for those loads with
@@ -93,7 +118,7 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
                                                                    int n_mels, int tiles_per_clip, int n_tiles,
                                                                    const MelTables* __restrict__ tab, float* __restrict__ out,
                                                                    unsigned* __restrict__ clip_max_key, float* __restrict__ tile_min,
-                                                                   int n_chunks) {
+                                                                   int n_chunks, const int* __restrict__ valid_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* Ltw = reinterpret_cast<float2*>(smem + OFF_TW);
     int* Lmi = reinterpret_cast<int*>(smem + OFF_MI);
@@ -123,15 +148,12 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
     unsigned long long lm_prev = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-    // Work item -> (clip, tile of the clip).  Items are dealt so that concurrently running workgroups (consecutive items)
-    // cover MANY clips, four neighbouring tiles of each: with a clip's 125 tiles on 125 neighbouring workgroups, the 500
-    // waves of a clip all merged their maximum into ONE word at the same time, and an atomic on a contended word
-    // completes at ~90 per microsecond -- behind which, in issue order, the wave's next loads waited (0.14 of 0.49 ms).
-    // Four neighbours still share their overlapping samples and complete each other's 128-byte output lines in L2.
-    constexpr int TGROUP = 4;
+    // Work items: see item_clip_of.  Dealt so that concurrently running workgroups (consecutive items) cover MANY clips:
+    // with a clip's 125 tiles on 125 neighbouring workgroups, the 500 waves of a clip all merged their maximum into ONE
+    // word at the same time (0.14 of 0.49 ms, see store_tile).
     const int n_clips = n_tiles / (TGROUP * ((tiles_per_clip + TGROUP - 1) / TGROUP));
-    auto item_clip = [&](int item) { return (item % (TGROUP * n_clips)) / TGROUP; };
-    auto item_tile = [&](int item) { return (item / (TGROUP * n_clips)) * TGROUP + item % TGROUP; };  // may be >= tiles_per_clip
+    auto item_clip = [&](int item) { return item_clip_of(item, n_clips); };
+    auto item_tile = [&](int item) { return item_tile_of(item, n_clips); };
 
     // samples of the lane's frame pair of one tile (center=True, reflect padding; torch.stft semantics): n = 20 n1 + j
     auto load_samples = [&](int tile, float (&re)[20], float (&im)[20]) {
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
     };
     const __amdgpu_buffer_rsrc_t rs_min = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(tile_min), 0, tile_min ? n_clips * tiles_per_clip * NWAVES * 4 : 0, 0x00020000);  // none: all dropped
-    auto store_tile = [&](int tile_or_none) {
+    auto store_tile = [&](int tile_or_none, bool silent = false) {
         // tile_or_none < 0 (a workgroup's first pass): the same instructions with every lane out of range, so that the
         // loop body has ONE instruction stream -- a branch around the stores would bring back the uncountable case
         const bool valid = tile_or_none >= 0;
@@ -226,7 +248,8 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
         vmax = wave_max(vmax);
         vmin = -wave_max(-vmin);
         // this wave's minimum (log10 units, +inf when it stored nothing) of the tile: slot [clip][tile][wave]
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vmin), rs_min,
+        // (a tile skipped as padding is marked with -inf: the finish kernel then knows it is constant and need not read it)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(silent ? -INFINITY : vmin), rs_min,
                                               valid && lane == 0 ? ((clip * tiles_per_clip + tt) * NWAVES + wv) * 4 : 0x7fffffff, 0, 0);
         if (valid) {  // wave-uniform
             if (clip != run_clip) {
@@ -241,12 +264,28 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
 
     float re[20], im[20];
     int prev_tile = -1;
+    bool prev_silent = false;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (item_tile(tile) >= tiles_per_clip) continue;  // padding item of the last group of four (the whole workgroup skips)
+        // A tile that lies entirely in a clip's zero padding (the caller passed the clips' valid lengths): every frame is
+        // exactly silence, i.e. log10(1e-10) = -10 in every filter -- what the full computation gives bit for bit -- so
+        // the samples are neither loaded nor transformed.  (Workgroup-uniform.  The rotation of the clips over the rounds
+        // evens the clips' lengths out over the workgroups; an exact balance by a compacted work list was measured: its
+        // one-workgroup scan costs 49 us per call, more than the 16 us it takes off the tile kernel at 256 clips.)
+        if (valid_len && tile_is_padding(item_tile(tile), valid_len[item_clip(tile)], n_samples)) {
+            store_tile(prev_tile, prev_silent);
+            prev_tile = tile;
+            prev_silent = true;
+            __syncthreads();  // staging free
+            for (int i = lane; i < n_mels * FPW; i += 64) stage[(i / FPW) * TILE_F + FPW * wv + i % FPW] = -10.0f;
+            __syncthreads();  // staging complete
+            continue;
+        }
         LSTAMP(9);  // loop overhead / previous tile's tail
         load_samples(tile, re, im);
-        store_tile(prev_tile);  // behind this tile's loads: see store_tile
+        store_tile(prev_tile, prev_silent);  // behind this tile's loads: see store_tile
         prev_tile = tile;
+        prev_silent = false;
         LSTAMP(7);  // store pass (of the previous tile)
         LSTAMP(0);  // sample loads (what is left exposed of them)
         fft400_stage1(re, im, win, Ltw, j);
@@ -349,7 +388,7 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
         __syncthreads();  // the staging image is complete; it is stored at the top of the next tile (store_tile)
         LSTAMP(6);  // barrier: staging complete
     }
-    if (prev_tile >= 0) store_tile(prev_tile);
+    if (prev_tile >= 0) store_tile(prev_tile, prev_silent);
     flush_max();
 #ifdef ASRK_STAMPS
     if (tid == 0 && blockIdx.x < 1024)
@@ -357,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS, LOGMEL_WPS) void logmel_tile_kernel(const
 #endif
 }
 
-using tile_kernel_t = void (*)(const float*, int, int, int, int, int, const MelTables*, float*, unsigned*, float*, int);
+using tile_kernel_t = void (*)(const float*, int, int, int, int, int, const MelTables*, float*, unsigned*, float*, int, const int*);
 // vec: rows of the output are 16-byte aligned (n_frames % 4 == 0): float4 stores
 tile_kernel_t tile_kernel_for(int n_mels, bool vec) {
     switch ((n_mels + 41) / 42) {
@@ -380,14 +419,20 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ 
                                                              int tiles_per_clip) {
     const int clip = blockIdx.y, grp = blockIdx.x;
     const float floor_x = ordered_value(key[(size_t)clip * KEY_STRIDE]) - 8.0f;
+    bool fill = false;  // every tile of the group was skipped as padding: constant -10, nothing to read
     if (tile_min) {
         const int t_lo = grp * FIN_TILES, t_hi = min(t_lo + FIN_TILES, tiles_per_clip);
-        float m = INFINITY;
-        for (int i = t_lo * NWAVES + (int)threadIdx.x; i < t_hi * NWAVES; i += 256)
-            m = fminf(m, tile_min[(size_t)clip * tiles_per_clip * NWAVES + i]);
+        float m = INFINITY, mm = -INFINITY;
+        for (int i = t_lo * NWAVES + (int)threadIdx.x; i < t_hi * NWAVES; i += 256) {
+            const float v = tile_min[(size_t)clip * tiles_per_clip * NWAVES + i];
+            m = fminf(m, v);
+            mm = fmaxf(mm, v);
+        }
         if (!__syncthreads_or(m < floor_x)) return;
+        fill = !__syncthreads_or(mm != -INFINITY);
     }
     const float floor_y = (floor_x + 4.0f) * 0.25f;
+    const float fill_y = fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
     float* o = out + (size_t)clip * n_mels * n_frames;
     const int f_lo = grp * FIN_TILES * TILE_F, f_hi = min(f_lo + FIN_TILES * TILE_F, n_frames);
     if (VEC4) {  // n_frames % 4 == 0: rows and segments are 16-byte aligned
@@ -395,6 +440,10 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ 
         for (int i = threadIdx.x; i < n_mels * w4; i += 256) {
             const int r = i / w4, c = i - r * w4;
             float4* q = reinterpret_cast<float4*>(o + (size_t)r * n_frames + f_lo) + c;
+            if (fill) {
+                *q = float4{fill_y, fill_y, fill_y, fill_y};
+                continue;
+            }
             float4 v = *q;
             v.x = fmaxf(v.x, floor_y); v.y = fmaxf(v.y, floor_y); v.z = fmaxf(v.z, floor_y); v.w = fmaxf(v.w, floor_y);
             *q = v;
@@ -404,7 +453,7 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ 
         for (int i = threadIdx.x; i < n_mels * w; i += 256) {
             const int r = i / w, c = i - r * w;
             float* q = o + (size_t)r * n_frames + f_lo + c;
-            *q = fmaxf(*q, floor_y);
+            *q = fill ? fill_y : fmaxf(*q, floor_y);
         }
     }
 }
@@ -514,8 +563,8 @@ extern "C" void asrk_logmel_plan_destroy(asrk_logmel_plan* plan) {
 namespace {
 // Both entry points: clear the per-clip maxima, tile kernel, finish kernel.  `prof`: bracket with events when the
 // measurement hook is on (event creation allocates, so the no-alloc entry point never does).
-int logmel_launch(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out, unsigned* clip_max_key,
-                  float* tile_min, bool prof_ok, hipStream_t st) {
+int logmel_launch(const asrk_logmel_plan* plan, const float* wave, const int* valid_len, int B, int n_samples, float* out,
+                  unsigned* clip_max_key, float* tile_min, bool prof_ok, hipStream_t st) {
     const int n_frames = n_samples / HOP;
     const auto kern = tile_kernel_for(plan->n_mels, (n_frames % 4) == 0);  // LDS opt-in: once per kernel, in plan_create
     if (!kern) return ASRK_ERR_SHAPE;
@@ -529,7 +578,8 @@ int logmel_launch(const asrk_logmel_plan* plan, const float* wave, int B, int n_
     const long resident = (long)LOGMEL_WPS * plan->n_cus;
     const int grid = (int)(n_tiles < resident ? n_tiles : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), tile_lds_bytes(plan->n_mels), st, wave, n_samples, n_frames,
-                       plan->n_mels, tiles_per_clip, (int)n_tiles, plan->tables, out, clip_max_key, tile_min, plan->n_chunks);
+                       plan->n_mels, tiles_per_clip, (int)n_tiles, plan->tables, out, clip_max_key, tile_min, plan->n_chunks,
+                       valid_len);
     ASRK_CHECK_HIP(hipGetLastError());
     const dim3 fgrid((tiles_per_clip + FIN_TILES - 1) / FIN_TILES, B);
     if ((n_frames & 3) == 0)
@@ -561,20 +611,19 @@ extern "C" size_t asrk_logmel_workspace_bytes(int B, int n_samples) {
     return ws_keys_bytes(B) + (size_t)B * tiles_per_clip * NWAVES * 4;
 }
 
-extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out, void* ws,
-                               size_t ws_bytes, void* stream) {
+extern "C" int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, const int* valid_samples, int B, int n_samples,
+                               float* out, void* ws, size_t ws_bytes, void* stream) {
     const int rc = logmel_check(plan, wave, B, n_samples, out);
+    if ((uintptr_t)valid_samples & 3) return ASRK_ERR_ALIGN;
     if (rc != ASRK_OK) return rc;
     if (B == 0) return ASRK_OK;
     if (!ws) return ASRK_ERR_NULL;
     if ((uintptr_t)ws & 255) return ASRK_ERR_ALIGN;
     if (ws_bytes < asrk_logmel_workspace_bytes(B, n_samples)) return ASRK_ERR_WORKSPACE;
-    return logmel_launch(plan, wave, B, n_samples, out, static_cast<unsigned*>(ws),
+    return logmel_launch(plan, wave, valid_samples, B, n_samples, out, static_cast<unsigned*>(ws),
                          reinterpret_cast<float*>(static_cast<char*>(ws) + ws_keys_bytes(B)), true, (hipStream_t)stream);
 }
 
-// The variant that allocates nothing (include/asrk.h): the per-clip maxima live in this device's copy of
-// g_noalloc_clip_max instead of a caller-provided workspace.  No hipMalloc / hipFree / event creation on this path.
 extern "C" int asrk_logmel_f32_noalloc(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples, float* out,
                                        void* stream) {
     const int rc = logmel_check(plan, wave, B, n_samples, out);
@@ -585,5 +634,5 @@ extern "C" int asrk_logmel_f32_noalloc(const asrk_logmel_plan* plan, const float
     if (dev != plan->device || !plan->noalloc_scratch) return ASRK_ERR_UNSUPPORTED;  // the scratch address is per device
     if (B == 0) return ASRK_OK;
     // no tile minima (they would need 2 KiB per clip of scratch): the finish kernel then visits every group
-    return logmel_launch(plan, wave, B, n_samples, out, plan->noalloc_scratch, nullptr, false, (hipStream_t)stream);
+    return logmel_launch(plan, wave, nullptr, B, n_samples, out, plan->noalloc_scratch, nullptr, false, (hipStream_t)stream);
 }

@@ -134,8 +134,12 @@ class LogMelFeatureExtractor:
             self._plans[dev.index] = h = handle
         return h
 
-    def extract_from_device(self, wave: torch.Tensor) -> torch.Tensor:
-        """wave: CUDA float32 [B, n_samples] (padded) -> CUDA float32 [B, n_mels, n_samples // 160]."""
+    def extract_from_device(self, wave: torch.Tensor, lengths=None) -> torch.Tensor:
+        """wave: CUDA float32 [B, n_samples] (padded) -> CUDA float32 [B, n_mels, n_samples // 160].
+
+        ``lengths`` (optional; array-like or tensor of B sample counts): the valid length of each clip in front of its
+        ZERO padding.  It changes no value -- the kernel only skips the transform of tiles that lie entirely in the
+        padding, which come out as exact silence either way."""
         _lib.assert_not_forked()
         if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_cuda:
             raise ValueError("expected a CUDA float32 tensor of shape [batch, n_samples]")
@@ -147,7 +151,12 @@ class LogMelFeatureExtractor:
         with torch.cuda.device(wave.device):
             out = torch.empty((B, self.feature_size, L // self.hop_length), dtype=torch.float32, device=wave.device)
             ws = torch.empty((max(int(lib.asrk_logmel_workspace_bytes(B, L)), 256),), dtype=torch.uint8, device=wave.device)
-            _lib.check(lib.asrk_logmel_f32(self._plan(wave.device), _lib.ptr(wave), B, L, _lib.ptr(out),
+            lens = None
+            if lengths is not None:
+                lens = torch.as_tensor(lengths).to(device=wave.device, dtype=torch.int32, non_blocking=True).contiguous()
+                if lens.numel() != B:
+                    raise ValueError(f"lengths has {lens.numel()} entries for a batch of {B}")
+            _lib.check(lib.asrk_logmel_f32(self._plan(wave.device), _lib.ptr(wave), _lib.ptr(lens), B, L, _lib.ptr(out),
                                            _lib.ptr(ws), ws.numel(), _lib.current_stream()), "asrk_logmel_f32")
         return out
 
@@ -190,7 +199,7 @@ class LogMelFeatureExtractor:
                                                    padding=padding, max_length=max_length)
         with torch.cuda.device(dev):
             wave = host.to(dev, non_blocking=True)
-            feats = self.extract_from_device(wave)
+            feats = self.extract_from_device(wave, lengths if self.padding_value == 0.0 else None)
         res = BatchFeature(input_features=feats)
         if return_attention_mask:
             res["attention_mask"] = torch.from_numpy(self.frame_mask(lengths, target)).to(dev, non_blocking=True)

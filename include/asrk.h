@@ -61,11 +61,15 @@ void asrk_logmel_plan_destroy(asrk_logmel_plan* plan);
 
 /* wave  dev f32 [B][n_samples]   (already padded/truncated, :300-307; n_samples > 200)
  * out   dev f32 [B][n_mels][n_samples/160]
+ * valid_samples  dev int32 [B] or NULL: the number of samples of each clip in front of its zero padding (the lengths
+ *       HF's padder works from, :300-307).  Only an accelerator: tiles that lie entirely in the padding are written as
+ *       silence (log10(1e-10), exactly what the transform gives for zeros) without being loaded or transformed; the
+ *       result is the same bit for bit, and samples at or after valid_samples[b] MUST be zero.
  * ws    dev scratch of asrk_logmel_workspace_bytes(B, n_samples), 256-byte aligned: the per-clip maxima (:160-162),
  *       one 128-byte line per clip, and one minimum per wave and tile, by which the floor pass skips what needs none.
  * STFT is Hann-400 / hop-160 / center + reflect pad; the last STFT frame is dropped (:154). */
 size_t asrk_logmel_workspace_bytes(int B, int n_samples);
-int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, int B, int n_samples,
+int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, const int* valid_samples, int B, int n_samples,
                     float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* The same computation for callers that cannot allocate -- code under HIP graph capture, tight serving loops,

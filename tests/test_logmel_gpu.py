@@ -116,3 +116,23 @@ def test_full_size_properties(extractors):
     f2 = fe.extract_from_device(w[:4] * 2.0)
     d = (f2 - f[:4])
     assert torch.allclose(d[:3], torch.full_like(d[:3], float(np.log10(4.0) / 4.0)), atol=2e-5)
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_valid_lengths_change_no_bit(extractors, n_mels):
+    """asrk_logmel_f32's optional `valid_samples`: tiles that lie entirely in a clip's zero padding are written as silence
+    without being transformed.  Same bits as the full computation, for lengths at tile and hop boundaries, a clip that
+    fills the window, an empty clip, and a non-multiple-of-24-frames window (reflection at the end)."""
+    fe = extractors[n_mels]
+    for total, lens in ((480000, [480000, 0, 1, 3839, 3840, 3841, 200000, 479599, 479999, 77777]),
+                        (100160, [100160, 50000, 96000, 99759, 99760, 123, 4000])):
+        g = torch.Generator(device="cuda").manual_seed(total)
+        w = (torch.randn((len(lens), total), device="cuda", generator=g) * 0.1).clamp_(-1, 1)
+        for i, n in enumerate(lens):
+            w[i, n:] = 0.0
+        full = fe.extract_from_device(w)
+        fast = fe.extract_from_device(w, lens)
+        assert torch.equal(full, fast)
+        assert torch.equal(fe.extract_from_device(w, torch.tensor(lens, device="cuda")), full)
+    with pytest.raises(ValueError):
+        fe.extract_from_device(w, [1, 2])

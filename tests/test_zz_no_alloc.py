@@ -25,7 +25,7 @@ def _both(lib, fe, wave):
     plan = fe._plan(wave.device)
     ref = torch.full((B, fe.feature_size, L // 160), float("nan"), device="cuda")
     ws = torch.empty((max(int(lib.asrk_logmel_workspace_bytes(B, L)), 256),), dtype=torch.uint8, device="cuda")
-    assert lib.asrk_logmel_f32(plan, _p(wave), B, L, _p(ref), _p(ws), ws.numel(), _stream()) == 0
+    assert lib.asrk_logmel_f32(plan, _p(wave), _p(None), B, L, _p(ref), _p(ws), ws.numel(), _stream()) == 0
     out = torch.full_like(ref, float("nan"))
     rc = lib.asrk_logmel_f32_noalloc(plan, _p(wave), B, L, _p(out), _stream())
     assert rc == 0, lib.asrk_strerror(rc)
