@@ -4,7 +4,7 @@
 #   bash tools/profile_all.sh [workloads...]      results under gpurun_out/profall/<workload>/
 set -e -o pipefail
 R=$GRAFT_REPO_ROOT
-WLS=${@:-pipeline-small pipeline-large train-large logmel logmel-128 splice}
+WLS=${@:-pipeline-small pipeline-large train-large logmel logmel-128 logmel-ragged splice}
 cd /tmp && export TMPDIR=/tmp
 for wl in $WLS; do
   O=$R/gpurun_out/profall/$wl
