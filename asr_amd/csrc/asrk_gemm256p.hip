@@ -299,8 +299,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     };
     const int wave_lds = wave * 1024;
     // half h of the X (W) DMAs of slice kt into X slot xs (W slot ws)
+#ifdef ASRK_ABLATE  // diagnostic builds only (tools/gemm_ablate.sh), after the prologue: 1 = no DMA, 2 = no
+    // fragment reads, 4 = every X DMA re-reads slice 0 of the first tile (cache hits), 8 = the same for W
+    bool ablate_on = false;
+#define ASRK_ABLATED(what) ((ASRK_ABLATE & (what)) && ablate_on)
+#else
+#define ASRK_ABLATED(what) false
+#endif
     auto stage_x = [&](int kt, int xs, auto hc) {
         constexpr int h = decltype(hc)::value;
+        if (ASRK_ABLATED(1)) return;
+        if (ASRK_ABLATED(4)) kt = 0;
         char* sb = smem + xs * SLOT;
         const char* xb = uniform_ptr(reinterpret_cast<const char*>(a.X) + (size_t)kt * (BK * 2));
 #pragma unroll
@@ -308,6 +317,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     };
     auto stage_w = [&](int kt, int ws, auto hc) {
         constexpr int h = decltype(hc)::value;
+        if (ASRK_ABLATED(1)) return;
+        if (ASRK_ABLATED(8)) kt = 0;
         char* sb = smem + WBASE + ws * SLOT;
         const char* wb = uniform_ptr(reinterpret_cast<const char*>(a.W) + (size_t)kt * (BK * 2));
 #pragma unroll
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     };
     auto read_x = [&](u32x4 (&dst)[HB], uint32_t base, auto mhc) {
         constexpr int mh = decltype(mhc)::value;
+        if (ASRK_ABLATED(2)) return;
         static_for<HB>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             dst[t] = lds_read16<(mh * HB + t) * 16 * RB>(base);
@@ -362,6 +374,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     };
     auto read_w = [&](auto gc, uint32_t base) {
         constexpr int g = decltype(gc)::value;
+        if (ASRK_ABLATED(2)) return;
         W[g] = lds_read16<g * 16 * RB>(base);
     };
     auto even_phase = [&](uint32_t xbase) {  // xbase = xa[ks] + X slot offset
@@ -442,6 +455,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     int xs = 0, ws = 0;                      // slots of the slice being multiplied
     bool x_behind = true;                    // the youngest GX DMAs in flight are an X batch for the slice after next
     first_reads(0, 0);
+#ifdef ASRK_ABLATE
+    ablate_on = true;
+#endif
 #ifdef ASRK_STAMPS
     int tile_no = 0;
 #endif
@@ -486,12 +502,12 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
                     if (extra_x) { stage_x(2, xs_prev, I0{}); stage_x(2, xs_prev, I1{}); }
                     // the sources switch to the next tile where its first slice is staged (at K = 192 the X switch and
                     // the late X batch of this tile fall into the same phase: the late batch goes first)
-                    if (has_next && kt + 2 == nkt) set_w(n0n);
+                    if (has_next && kt + 2 == nkt && !ASRK_ABLATED(8)) set_w(n0n);
                     if (w_kt >= 0) stage_w(w_kt, ws, I0{});
                 } else if (g == 1) {
                     if (w_kt >= 0) stage_w(w_kt, ws, I1{});
                 } else if (g == 2) {
-                    if (has_next && kt + 3 == nkt) set_x(m0n);
+                    if (has_next && kt + 3 == nkt && !ASRK_ABLATED(4)) set_x(m0n);
                     if (x_kt >= 0) stage_x(x_kt, xs, I0{});
                 } else {
                     if (x_kt >= 0) stage_x(x_kt, xs, I1{});
