@@ -329,11 +329,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
 
-    f32x4 acc[4][MT];  // [nt][mt]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4][MT];  // [nt][mt]; first written by the MFMAs of a tile's first k-step (see group)
 
     const int frow = lane & 15, fq = lane >> 4;
     constexpr int HB = MT / 2;  // 16-row X fragments per half of the wave's rows
@@ -356,12 +352,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
     }
     u32x4 W[4], X[HB], Xn[HB];
     auto tie = [](u32x4& r) { asm volatile("" : "+v"(r)); };
-    auto group = [&](auto gc, auto mhc, u32x4 (&xs_)[HB]) {
+    // FIRST (k-step 0 of a tile's first slice): the MFMA takes the constant 0 as C, so the accumulators are never
+    // cleared -- 128 moves per wave and tile that ran between two tiles with the matrix pipe idle
+    auto group = [&](auto gc, auto mhc, u32x4 (&xs_)[HB], auto first_c) {
         constexpr int g = decltype(gc)::value, mh = decltype(mhc)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
 #pragma unroll
         for (int t = 0; t < HB; ++t)
             acc[g][mh * HB + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, W[g]), __builtin_bit_cast(bf16x8, xs_[t]), acc[g][mh * HB + t], 0, 0, 0);
+                __builtin_bit_cast(bf16x8, W[g]), __builtin_bit_cast(bf16x8, xs_[t]),
+                FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g][mh * HB + t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto read_x = [&](u32x4 (&dst)[HB], uint32_t base, auto mhc) {
@@ -377,41 +377,41 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         if (ASRK_ABLATED(2)) return;
         W[g] = lds_read16<g * 16 * RB>(base);
     };
-    auto even_phase = [&](uint32_t xbase) {  // xbase = xa[ks] + X slot offset
+    auto even_phase = [&](uint32_t xbase, auto first_c) {  // xbase = xa[ks] + X slot offset
         asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < HB; ++t) tie(X[t]);
         tie(W[0]);
-        group(I0{}, I0{}, X);
+        group(I0{}, I0{}, X, first_c);
         read_x(Xn, xbase, I1{});
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(HB + 2) : "memory");
         tie(W[1]);
-        group(I1{}, I0{}, X);
+        group(I1{}, I0{}, X, first_c);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(HB + 1) : "memory");
         tie(W[2]);
-        group(I2{}, I0{}, X);
+        group(I2{}, I0{}, X, first_c);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(HB) : "memory");
         tie(W[3]);
-        group(I3{}, I0{}, X);
+        group(I3{}, I0{}, X, first_c);
     };
     // `pre` runs between the wait for Xn and the MFMAs (phase D: the barrier); `mid(g)` behind MFMA group g (phase D:
     // part of the next DMA batch each, so that their issue -- 40-75 cycles apiece -- falls under MFMAs in flight
     // instead of all of them following the barrier back to back on both waves of the SIMD at once)
-    auto odd_phase = [&](uint32_t xnext, uint32_t wnext, bool reads, auto&& pre, auto&& mid) {
+    auto odd_phase = [&](uint32_t xnext, uint32_t wnext, bool reads, auto first_c, auto&& pre, auto&& mid) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < HB; ++t) tie(Xn[t]);
         pre();
-        group(I0{}, I1{}, Xn);
+        group(I0{}, I1{}, Xn, first_c);
         mid(I0{});
         if (reads) { read_x(X, xnext, I0{}); read_w(I0{}, wnext); }
-        group(I1{}, I1{}, Xn);
+        group(I1{}, I1{}, Xn, first_c);
         mid(I1{});
         if (reads) read_w(I1{}, wnext);
-        group(I2{}, I1{}, Xn);
+        group(I2{}, I1{}, Xn, first_c);
         mid(I2{});
         if (reads) read_w(I2{}, wnext);
-        group(I3{}, I1{}, Xn);
+        group(I3{}, I1{}, Xn, first_c);
         mid(I3{});
         if (reads) read_w(I3{}, wnext);
     };
@@ -472,16 +472,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         const int m0n = has_next ? (tm_lo + tnext / tiles_n) * BM : 0;
         const int n0n = has_next ? (tnext % tiles_n) * BN : 0;
         const bool late_x = t != lidx;  // not the first tile: X of slice 2 is still to be staged (see above)
-#pragma nounroll
-        for (int kt = 0; kt < nkt; ++kt) {
+        auto slice = [&](int kt, auto first_c) {
 #ifdef ASRK_STAMPS
             if (kt == 0) { if (tile_no == 0) PSTAMP(1); else if (tile_no == 1) PSTAMP(5); }
 #endif
             const int xs1 = xs == NXS - 1 ? 0 : xs + 1;
             const uint32_t xso = xs * SLOT, wso = ws * SLOT;
-            even_phase(xa[0] + xso);                                                    // A
-            odd_phase(xa[1] + xso, wa[1] + wso, true, [] {}, [](auto) {});              // B
-            even_phase(xa[1] + xso);                                                    // C
+            even_phase(xa[0] + xso, first_c);                                           // A
+            odd_phase(xa[1] + xso, wa[1] + wso, true, first_c, [] {}, [](auto) {});     // B
+            even_phase(xa[1] + xso, std::false_type{});                                 // C
             // D: W of slice j + 2 -> W slot ws; X of slice j + 3 -> X slot xs (not behind a tile's last slice: the
             // epilogue patches go there); behind the first slice of a later tile also the X batch left out then
             int w_kt = -1, x_kt = -1;
@@ -490,7 +489,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
             const bool extra_x = late_x && kt == 0;
             const int xs_prev = xs == 0 ? NXS - 1 : xs - 1;
             const bool xb_now = x_behind;
-            odd_phase(xa[0] + xs1 * SLOT, wa[0] + (ws ^ 1) * SLOT, kt + 1 < nkt,
+            odd_phase(xa[0] + xs1 * SLOT, wa[0] + (ws ^ 1) * SLOT, kt + 1 < nkt, std::false_type{},
                       [&] {
                           // slice j + 1 complete: everything but the X batch issued last, if there is one
                           if (xb_now) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GX) : "memory");
@@ -515,7 +514,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
             });
             x_behind = x_kt >= 0;
             if (kt + 1 < nkt) { xs = xs1; ws ^= 1; }
-        }
+        };
+        slice(0, std::true_type{});
+#pragma nounroll
+        for (int kt = 1; kt < nkt; ++kt) slice(kt, std::false_type{});
         // xs / ws are still the slots of the last slice: X slot xs holds the patches now
         char* const patch = smem + xs * SLOT + wave * PATCH;
         {
@@ -535,10 +537,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         ++tile_no;
 #endif
         if (!has_next) break;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         t = tnext;
         m0 = m0n;
         n0 = n0n;
