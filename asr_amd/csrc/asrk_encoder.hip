@@ -241,6 +241,8 @@ int asrk_encoder_forward_impl(const asrk_encoder* enc, const float* feats, int B
     if (B <= 0 || B > 65535) return ASRK_ERR_SHAPE;
     if (((uintptr_t)feats & 15) || ((uintptr_t)out & 15) || ((uintptr_t)ws & 255)) return ASRK_ERR_ALIGN;
     const asrk_encoder_dims& dm = enc->dims;
+    // the fused tail writes [M][d_model] bf16 into a slot the caller sized [M][tail->dim] and reads gamma[d_model]
+    if (tail && (tail->dim != dm.d_model || !tail->gamma || !tail->xn)) return tail->dim != dm.d_model ? ASRK_ERR_SHAPE : ASRK_ERR_NULL;
     const int d = dm.d_model, F = dm.ffn_dim, C = dm.n_mels, H = dm.n_heads;
     const WsLayout wl = ws_layout(dm, B);
     if (ws_bytes < wl.total) return ASRK_ERR_WORKSPACE;

@@ -109,6 +109,7 @@ struct AsrkRmsTail {
     bf16_t* xn;          // [M][D] bf16: gamma * y * rstd, the operand of linear_1
     float* rstd;         // [M] or null
     float eps;
+    int dim;             // row width the caller sized xn / gamma for (the projector's audio_dim): must equal d_model
 };
 // x (+ delta, may be null) -> LayerNorm -> y (written to y_out unless null) -> RMSNorm -> t.xn, t.rstd
 int asrk_launch_layernorm_rms(const float* x, const bf16_t* delta, const float* w, const float* b, float* y_out,

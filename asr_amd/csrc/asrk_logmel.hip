@@ -601,6 +601,11 @@ int logmel_check(const asrk_logmel_plan* plan, const float* wave, int B, int n_s
     if (((uintptr_t)out & 15) || ((uintptr_t)wave & 3)) return ASRK_ERR_ALIGN;
     if (n_samples / HOP < 1 || B > 65535) return ASRK_ERR_SHAPE;
     if ((long)plan->n_mels * (n_samples / HOP) >= (1L << 29)) return ASRK_ERR_SHAPE;  // 32-bit byte offsets inside a clip's features
+    // the plan's tables (and the no-alloc scratch) live on the device that was current in asrk_logmel_plan_create: a launch
+    // from another device would hand its kernels the wrong GPU's addresses
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return ASRK_ERR_HIP;
+    if (dev != plan->device) return ASRK_ERR_UNSUPPORTED;
     return ASRK_OK;
 }
 }  // namespace
@@ -629,9 +634,7 @@ extern "C" int asrk_logmel_f32_noalloc(const asrk_logmel_plan* plan, const float
     const int rc = logmel_check(plan, wave, B, n_samples, out);
     if (rc != ASRK_OK) return rc;
     if (B > ASRK_LOGMEL_NOALLOC_MAX_CLIPS) return ASRK_ERR_WORKSPACE;  // beyond the static scratch: use asrk_logmel_f32
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return ASRK_ERR_HIP;
-    if (dev != plan->device || !plan->noalloc_scratch) return ASRK_ERR_UNSUPPORTED;  // the scratch address is per device
+    if (!plan->noalloc_scratch) return ASRK_ERR_UNSUPPORTED;  // (logmel_check has compared the plan's device with the current one)
     if (B == 0) return ASRK_OK;
     // no tile minima (they would need 2 KiB per clip of scratch): the finish kernel then visits every group
     return logmel_launch(plan, wave, nullptr, B, n_samples, out, plan->noalloc_scratch, nullptr, false, (hipStream_t)stream);

@@ -391,6 +391,7 @@ extern "C" int asrk_encoder_projector_forward(const asrk_encoder* enc, const flo
     AsrkRmsTail tail;
     tail.gamma = p->gamma;
     tail.eps = RMS_EPS;
+    tail.dim = d->audio_dim;  // checked against the encoder's d_model before anything is launched
     xn_slot(d->audio_dim, d->text_dim, M, saved, ws, &tail.xn, &tail.rstd);
     if ((rc = asrk_encoder_forward_impl(enc, feats, B, n_frames, hidden, &tail, enc_ws, enc_ws_bytes, st)) != ASRK_OK) return rc;
     return forward_from_xn(d, p, M, out, out_dtype, saved, ws, st);

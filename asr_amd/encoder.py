@@ -111,7 +111,9 @@ class WhisperEncoder(nn.Module):
     # .to() / .cuda() / .float() (``_apply``) and ``load_state_dict`` mark it stale -- and through in-place edits of
     # the two sentinel parameters checked on every call (the first and the last one).  The full (address, version) key
     # over all ~200-500 parameters costs 0.2-1.2 ms of host time per forward, so it is taken only when one of those
-    # says something changed; after an in-place edit of some OTHER frozen weight call ``refresh_weights()``.
+    # says something changed, on every train() / eval() switch, and on every 256th call; after an in-place edit of some
+    # OTHER frozen weight call ``refresh_weights()`` to have it seen at once.  Updates through ``p.data`` bump no
+    # version counter and are seen by nothing: call ``refresh_weights()`` after those.
     def _apply(self, fn, *args, **kwargs):
         self._stale = True
         return super()._apply(fn, *args, **kwargs)
@@ -119,6 +121,11 @@ class WhisperEncoder(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self._stale = True
         return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode: bool = True):
+        # a mode switch is where fine-tuning code tends to touch weights: take the full key again on the next call
+        self._stale = True
+        return super().train(mode)
 
     def refresh_weights(self):
         """Re-pack the frozen weights on the next forward (needed only after editing them in place)."""
@@ -129,8 +136,12 @@ class WhisperEncoder(nn.Module):
         a, b = enc.conv1.weight, enc.layer_norm.bias
         return (a.data_ptr(), a._version, b.data_ptr(), b._version)
 
+    _FULL_CHECK_EVERY = 256  # calls between two full (address, version) keys over every parameter
+
     def _pack(self):
-        if self._handle is not None and not self._stale and self._sentinel() == self._packed_sentinel:
+        self._calls = getattr(self, "_calls", 0) + 1
+        if (self._handle is not None and not self._stale and self._sentinel() == self._packed_sentinel
+                and self._calls % self._FULL_CHECK_EVERY):
             return self._handle
         enc = self.whisper.encoder
         params = list(enc.parameters())

@@ -83,6 +83,8 @@ class _ProjectorFn(torch.autograd.Function):
             out_shape = (*x.shape[:-1], T)
             need_grad = need_grad or (grad_enabled and ctx.needs_input_grad[0])
         else:
+            if encoder.d_model != A:
+                raise ValueError(f"projector audio_dim {A} does not match the encoder's d_model {encoder.d_model}")
             feats, handle, enc_ws = encoder._prepare(x)
             out_shape = (feats.shape[0], 1500, T)
             x2 = torch.empty((feats.shape[0] * 1500, A), dtype=torch.float32, device=feats.device) if need_grad else None
@@ -154,6 +156,11 @@ class AudioProjector(nn.Module):
         nn.init.zeros_(self.linear_2.bias)
         self.out_dtype = out_dtype  # None: fp32, or bf16 under torch.autocast(bfloat16) like the reference
         self._packed = _PackedWeights()
+
+    def refresh_weights(self):
+        """Re-make the bf16 weight copies on the next call.  Needed only after an update that bumps no version counter
+        (``p.data.copy_()`` / ``p.data.add_()``, as some sharding wrappers and third-party optimizers do)."""
+        self._packed.key = None
 
     def _out_dtype(self):
         if self.out_dtype is not None:

@@ -23,6 +23,7 @@ Workloads (BASELINE.json configs):
   splice          SURVEY 8(f2): the embed splice of ASRModel.forward alone, 64 samples (HBM-bound copy)
   stub            no GPU: a small CPU matmul per step over gloo; exists so that the launcher, the barriers and the
                   max-over-ranks timing can be tested at world size 2 without a GPU (tests/test_bench_launcher.py)
+  stub-train      no GPU: train-large's control flow (FlatGradAllReducer, every pass that calls step()) on a tiny CPU model
 """
 import argparse
 import json
@@ -56,6 +57,10 @@ WORKLOADS = {
     # positions) x 960 (SmolLM2-360M width), bf16 like the decoder; HBM-bound copy
     "splice": dict(batch=64, text_len=64, text_dim=960),
     "stub": dict(batch=4),
+    # the train step's sequence of collectives (timed steps, instrumented steps, the all-reduce timing steps) on a CPU
+    # stand-in for the projector over gloo: tests/test_bench_launcher.py checks at world size 2 that no rank issues a
+    # collective the others do not
+    "stub-train": dict(batch=4, train=True),
 }
 
 
@@ -181,19 +186,26 @@ def cpu_baseline(wname, w):
 
 
 def pmc_traffic(workload, batch, kernel):
-    """HBM bytes per launch of the dominant kernel, from the PMC passes committed under profiles/
-    (tools/pmc_traffic.py; rocprofv3 cannot run inside this process).  None when no pass matches this
-    workload and batch."""
+    """(HBM bytes per launch of the dominant kernel, provenance) from the PMC passes committed under profiles/
+    (tools/pmc_traffic.py; rocprofv3 cannot run inside this process).  (None, None) when no pass matches this workload
+    and batch.  The provenance names the file and its git blob hash, so a line can be matched to the committed pass."""
+    import hashlib
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
     try:
-        with open(path) as fh:
-            t = json.load(fh)
+        with open(path, "rb") as fh:
+            raw = fh.read()
+        t = json.loads(raw)
     except (OSError, ValueError):
-        return None
+        return None, None
     if t.get("workload") != workload or t.get("clips_per_gpu") != batch:
-        return None
-    k = t.get("kernels", {}).get(kernel.split("+")[0])
-    return k["bytes_per_launch"] if k else None
+        return None, None
+    k = t.get("kernels", {}).get(kernel)
+    if not k:
+        return None, None
+    blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()  # == `git hash-object profiles/hbm_traffic.json`
+    return k["bytes_per_launch"], {"file": "profiles/hbm_traffic.json", "git_blob": blob,
+                                   "note": "separate rocprofv3 --pmc passes of this command, not collected in this run"}
 
 
 def free_port():
@@ -202,11 +214,15 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, deadline_s=600.0):
     """`python bench.py --gpus N` without a launcher around it: start N fresh processes of this script, one per GPU,
     with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, BEFORE this process has made any GPU call (it
     never makes one: a process that has initialised the GPU must not be replaced or forked).  Rank 0's stdout -- the one
-    JSON line -- is relayed; the exit code is non-zero if any rank fails."""
+    JSON line -- is drained by a thread while EVERY child is polled: as soon as one rank exits non-zero (or the deadline
+    passes) the others, which would sit in a barrier for as long as the collective's own timeout, are killed and the
+    launcher returns non-zero within a fraction of a second."""
+    import threading
+
     port = free_port()
     procs = []
     for r in range(n):
@@ -215,34 +231,42 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this pool
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read()  # EOF when rank 0 exits
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)  # EOF when rank 0 exits
+    reader.start()
     rcs = [None] * n
-    deadline = time.time() + 600
-    while any(rc is None for rc in rcs) and time.time() < deadline:
+    deadline = time.time() + deadline_s
+    timed_out = False
+    while any(rc is None for rc in rcs):
         for i, p_ in enumerate(procs):
             if rcs[i] is None:
                 rcs[i] = p_.poll()
         if any(rc not in (None, 0) for rc in rcs):
             break  # one rank failed: the others would wait at a barrier for ever
+        if time.time() > deadline:
+            timed_out = True
+            break
         time.sleep(0.05)
     for i, p_ in enumerate(procs):  # stop exactly the children started above that are still running
         if rcs[i] is None:
             p_.kill()
             rcs[i] = p_.wait()
+    reader.join(timeout=10)
+    out0 = b"".join(chunks)
     for line in out0.decode(errors="replace").splitlines():
         # the one JSON line goes to stdout; whatever else a library printed there (gloo / libdrm notices) to stderr
         print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
     sys.stdout.flush()
     bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    if bad or timed_out:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}" + (" [deadline passed]" if timed_out else ""), file=sys.stderr)
         return 1
     return 0
 
 
 # rocprof symbol of each profiling category of the library (include/asrk.h, asrk_profile_read)
 PROF_SYMBOLS = {0: "gemm256p_kernel", 5: "gemm256_kernel", 6: "gemm_bf16_kernel", 1: "attention_kernel",
-                2: "logmel_kernel", 3: "layernorm_kernel", 4: "splice_fwd_kernel"}
+                2: "logmel_tile_kernel+logmel_finish_kernel", 3: "layernorm_kernel", 4: "splice_fwd_kernel"}
 PROF_FLOPS = (0, 5, 6, 1)
 
 
@@ -271,7 +295,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    on_gpu = args.workload != "stub"
+    on_gpu = not args.workload.startswith("stub")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -283,6 +307,8 @@ def main():
         else:
             dist.init_process_group("gloo")
         world = dist.get_world_size()  # what is reported is what actually runs
+        if os.environ.get("ASRK_BENCH_TEST_FAIL_RANK") == str(rank):
+            sys.exit(3)  # test hook (tests/test_bench_launcher.py): a rank that dies after the group exists
     elif on_gpu:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
@@ -363,16 +389,33 @@ def main():
     elif w.get("train"):
         from asr_amd.distributed import FlatGradAllReducer
 
-        enc, proj = seeded_models(w, device)
+        if on_gpu:
+            enc, proj = seeded_models(w, device)
+            # the decoder is outside this path: its gradient w.r.t. the audio embeddings is a fixed synthetic tensor
+            g_up = (torch.randn((B, 1500, w["text_dim"]), device=device) * 1e-2).to(torch.bfloat16)
+
+            def fwd():
+                return encode_and_project(enc, proj, features())  # the encoder runs under no_grad (src/modeling.py:33-40)
+        else:  # stub-train: the same control flow on a CPU stand-in
+            torch.manual_seed(0)
+            proj = torch.nn.Linear(64, 64)
+            x_cpu = torch.randn((B, 64), generator=torch.Generator().manual_seed(rank))
+            g_up = torch.ones((B, 64))
+
+            def fwd():
+                return proj(x_cpu)
         reducer = FlatGradAllReducer(proj.parameters()) if dist is not None else None
-        # the decoder is outside this path: its gradient w.r.t. the audio embeddings is a fixed synthetic tensor
-        g_up = (torch.randn((B, 1500, w["text_dim"]), device=device) * 1e-2).to(torch.bfloat16)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         timing = {"on": False}
 
+        def now():  # GPU: an event on the current stream; CPU: the host clock
+            if on_gpu:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                return e
+            return time.perf_counter()
+
         def step():
-            feats = features()
-            emb = encode_and_project(enc, proj, feats)  # the encoder runs under no_grad (src/modeling.py:33-40)
+            emb = fwd()
             if reducer is not None:
                 reducer.zero_()  # .grad tensors are views of the reducer's flat buffer
             else:
@@ -380,13 +423,16 @@ def main():
                     p_.grad = None
             emb.backward(g_up)
             if reducer is not None:
-                if timing["on"]:
-                    ev[0].record()
+                t_a = now() if timing["on"] else None
                 reducer.all_reduce()
+                timing["calls"] = timing.get("calls", 0) + 1
                 if timing["on"]:
-                    ev[1].record()
-                    ev[1].synchronize()
-                    comm_ms.append(ev[0].elapsed_time(ev[1]))
+                    t_b = now()
+                    if on_gpu:
+                        t_b.synchronize()
+                        comm_ms.append(t_a.elapsed_time(t_b))
+                    else:
+                        comm_ms.append((t_b - t_a) * 1e3)
             return emb.detach()
     else:
         enc, proj = seeded_models(w, device)
@@ -424,13 +470,19 @@ def main():
     # ---- instrumented pass (rank 0): HIP events around every launch of the hot kernels, on their launch stream
     roofline = None
     stages = {}
-    if rank == 0 and on_gpu:
+    if on_gpu or w.get("train"):
+        # EVERY rank runs these steps (train-large's step contains the gradient all-reduce: the ranks' sequences of
+        # collectives must stay identical); only rank 0 switches the event hook on and reads it
         n_inst = min(args.steps, 3)
-        lib.asrk_profile_enable(1)
+        if rank == 0 and on_gpu:
+            lib.asrk_profile_enable(1)
         for _ in range(n_inst):
             step()
-        torch.cuda.synchronize()
-        lib.asrk_profile_enable(0)
+        if on_gpu:
+            torch.cuda.synchronize()
+        if rank == 0 and on_gpu:
+            lib.asrk_profile_enable(0)
+    if rank == 0 and on_gpu:
         tot = {}
         fam = {}
         for cat, nm in PROF_SYMBOLS.items():
@@ -461,7 +513,7 @@ def main():
             ach = work / (ms * 1e-3) / 1e9
             roofline = dict(bound="hbm", kernel=PROF_SYMBOLS[dom], achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=ach / PEAK_HBM_GBS, traffic=None, avg_launch_us=ms * 1e3 / n, launches=n)
-        roofline["traffic"] = pmc_traffic(args.workload, B, roofline["kernel"])
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(args.workload, B, roofline["kernel"])
     if comm_ms is not None and w.get("train") and dist is not None:
         # the collective's own time, outside the timed region: three more steps with events around the all-reduce
         timing["on"] = True
@@ -469,6 +521,11 @@ def main():
             step()
         timing["on"] = False
         barrier()
+        # every rank must have issued the same number of gradient all-reduces (reported, and checked by the gloo test)
+        cnt = torch.tensor([timing.get("calls", 0)], device=device, dtype=torch.int64)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        allreduce_calls = [int(c.item()) for c in cnts]
     if rank == 0:
         clip_s = 30.0 if valid_lens is None else float(valid_lens.sum().item()) / 16000.0 / B  # mean valid seconds (rank 0's)
         value = world * B * clip_s * args.steps / dt
@@ -476,7 +533,7 @@ def main():
             "metric": METRIC, "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_ranks": rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.workload.startswith("logmel") or args.workload == "stub" else "bf16", "data": "synthetic",
+            "dtype": "f32" if args.workload.startswith("logmel") or not on_gpu else "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "clips_per_gpu": B, "clip_seconds": round(clip_s, 2), "window_seconds": 30,
                        "global_batch": world * B,
                        **{k: v for k, v in w.items() if k != "batch"},
@@ -485,6 +542,7 @@ def main():
         }
         if comm_ms:
             res["grad_allreduce_ms"] = float(np.median(comm_ms))
+            res["grad_allreduce_calls_ranks"] = allreduce_calls
         if args.host_input:
             res["data"] = "synthetic, copied from pinned host memory every step (diagnostic, not the contract's value)"
         if "d_model" in w:

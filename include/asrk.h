@@ -67,7 +67,9 @@ void asrk_logmel_plan_destroy(asrk_logmel_plan* plan);
  *       result is the same bit for bit, and samples at or after valid_samples[b] MUST be zero.
  * ws    dev scratch of asrk_logmel_workspace_bytes(B, n_samples), 256-byte aligned: the per-clip maxima (:160-162),
  *       one 128-byte line per clip, and one minimum per wave and tile, by which the floor pass skips what needs none.
- * STFT is Hann-400 / hop-160 / center + reflect pad; the last STFT frame is dropped (:154). */
+ * STFT is Hann-400 / hop-160 / center + reflect pad; the last STFT frame is dropped (:154).
+ * The plan's tables live on the device that was current in asrk_logmel_plan_create: a call made with another device
+ * current returns ASRK_ERR_UNSUPPORTED (one plan per GPU). */
 size_t asrk_logmel_workspace_bytes(int B, int n_samples);
 int asrk_logmel_f32(const asrk_logmel_plan* plan, const float* wave, const int* valid_samples, int B, int n_samples,
                     float* out, void* ws, size_t ws_bytes, void* stream);

@@ -77,19 +77,8 @@ def gen_logmel():
 
 
 # ------------------------------------------------------------------------------------ encoder
-ENCODER_CASES = {
-    # name: dict(d_model, layers, heads, ffn, n_mels, batch, feat_seed, rows)
-    "tiny": dict(d_model=128, layers=2, heads=2, ffn=512, n_mels=80, batch=2, seed=11, rows=None),
-    "mid": dict(d_model=256, layers=4, heads=4, ffn=1024, n_mels=128, batch=1, seed=12, rows=None),
-    "small": dict(d_model=768, layers=12, heads=12, ffn=3072, n_mels=80, batch=1, seed=13,
-                  rows=list(range(0, 1500, 25)) + [1, 2, 3, 749, 1496, 1497, 1498, 1499]),
-}
-
-
-def encoder_features(case):
-    c = ENCODER_CASES[case]
-    x = signals.det_normal((c["batch"], c["n_mels"], 3000), seed=c["seed"] * 7 + 1, std=0.45)
-    return np.clip(x, -1.0, 1.6).astype(np.float32)
+ENCODER_CASES = signals.ENCODER_CASES  # the cases and their inputs live in tests/signals.py
+encoder_features = signals.encoder_features
 
 
 def gen_encoder():
@@ -125,17 +114,8 @@ def gen_encoder():
 
 
 # ------------------------------------------------------------------------------------ projector
-PROJECTOR_CASES = {
-    "p128": dict(audio_dim=128, text_dim=192, batch=2, seed=21),
-    "p768": dict(audio_dim=768, text_dim=960, batch=1, seed=22),
-}
-
-
-def projector_inputs(case):
-    c = PROJECTOR_CASES[case]
-    x = signals.det_normal((c["batch"], 1500, c["audio_dim"]), seed=c["seed"] * 5 + 1, std=1.3)
-    gy = signals.det_normal((c["batch"], 1500, c["text_dim"]), seed=c["seed"] * 5 + 2, std=1.0)
-    return x, gy
+PROJECTOR_CASES = signals.PROJECTOR_CASES
+projector_inputs = signals.projector_inputs
 
 
 def gen_projector():

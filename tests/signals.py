@@ -130,3 +130,33 @@ def projector_state_dict(audio_dim: int, text_dim: int, seed: int = 0):
         "linear_2.weight": det_normal((text_dim, text_dim), b + 4, std=1.0),
         "linear_2.bias": det_normal((text_dim,), b + 5, std=0.02),
     }
+
+
+# ---------------------------------------------------------------------------- golden cases (inputs only)
+# The cases tests/golden/make_golden.py generated the fixtures for.  They live here, not in the generator, so that no
+# test imports the script that imports transformers / the reference (it never travels to the GPU box as a dependency).
+ENCODER_CASES = {
+    # name: dict(d_model, layers, heads, ffn, n_mels, batch, feat_seed, rows)
+    "tiny": dict(d_model=128, layers=2, heads=2, ffn=512, n_mels=80, batch=2, seed=11, rows=None),
+    "mid": dict(d_model=256, layers=4, heads=4, ffn=1024, n_mels=128, batch=1, seed=12, rows=None),
+    "small": dict(d_model=768, layers=12, heads=12, ffn=3072, n_mels=80, batch=1, seed=13,
+                  rows=list(range(0, 1500, 25)) + [1, 2, 3, 749, 1496, 1497, 1498, 1499]),
+}
+
+PROJECTOR_CASES = {
+    "p128": dict(audio_dim=128, text_dim=192, batch=2, seed=21),
+    "p768": dict(audio_dim=768, text_dim=960, batch=1, seed=22),
+}
+
+
+def encoder_features(case):
+    c = ENCODER_CASES[case]
+    x = det_normal((c["batch"], c["n_mels"], 3000), seed=c["seed"] * 7 + 1, std=0.45)
+    return np.clip(x, -1.0, 1.6).astype(np.float32)
+
+
+def projector_inputs(case):
+    c = PROJECTOR_CASES[case]
+    x = det_normal((c["batch"], 1500, c["audio_dim"]), seed=c["seed"] * 5 + 1, std=1.3)
+    gy = det_normal((c["batch"], 1500, c["text_dim"]), seed=c["seed"] * 5 + 2, std=1.0)
+    return x, gy

@@ -19,7 +19,6 @@ import pytest
 import torch
 
 from tests import signals
-from tests.golden import make_golden as mg
 
 pytestmark = pytest.mark.gpu
 
@@ -119,11 +118,11 @@ def test_whisper_small_encoder_at_bench_batch_matches_golden(golden_dir, margins
     tests/golden/encoder_small.npz (HF WhisperEncoder fp32, modeling_whisper.py:592-646); clips 1..63 are distinct."""
     from asr_amd.encoder import WhisperEncoder
 
-    c = mg.ENCODER_CASES["small"]
+    c = signals.ENCODER_CASES["small"]
     sd = signals.encoder_state_dict(c["d_model"], c["layers"], c["ffn"], c["n_mels"], seed=c["seed"])
     enc = WhisperEncoder.from_state_dict(sd, n_heads=c["heads"])
     g = np.load(f"{golden_dir}/encoder_small.npz")
-    x0 = torch.from_numpy(mg.encoder_features("small")).cuda()  # [1, 80, 3000]
+    x0 = torch.from_numpy(signals.encoder_features("small")).cuda()  # [1, 80, 3000]
     B = 64
     gen = torch.Generator(device="cuda").manual_seed(2024)
     x = (torch.randn((B, c["n_mels"], 3000), device="cuda", generator=gen) * 0.45).clamp_(-1.0, 1.6)

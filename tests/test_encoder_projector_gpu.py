@@ -11,7 +11,6 @@ import torch
 from oracle import encoder as oracle_encoder
 from oracle import projector as oracle_projector
 from tests import signals
-from tests.golden import make_golden as mg
 
 pytestmark = pytest.mark.gpu
 REL = 1e-2
@@ -26,7 +25,7 @@ def rel_l2(a, b):
 def build_encoder(case):
     from asr_amd.encoder import WhisperEncoder
 
-    c = mg.ENCODER_CASES[case]
+    c = signals.ENCODER_CASES[case]
     sd = signals.encoder_state_dict(c["d_model"], c["layers"], c["ffn"], c["n_mels"], seed=c["seed"])
     enc = WhisperEncoder.from_state_dict(sd, n_heads=c["heads"])
     return enc, sd, c
@@ -36,7 +35,7 @@ def build_encoder(case):
 def test_encoder_matches_golden(golden_dir, margins, case):
     enc, sd, c = build_encoder(case)
     g = np.load(f"{golden_dir}/encoder_{case}.npz")
-    x = torch.from_numpy(mg.encoder_features(case)).cuda()
+    x = torch.from_numpy(signals.encoder_features(case)).cuda()
     y = enc(x, attention_mask=torch.ones((x.shape[0], 3000), dtype=torch.int32, device="cuda"))
     assert y.dtype == torch.float32 and tuple(y.shape) == (c["batch"], 1500, c["d_model"]) and not y.requires_grad
     y = y.cpu().numpy()
@@ -58,8 +57,8 @@ def test_encoder_stem_and_layers_match_oracle():
     behind the final LayerNorm."""
     from asr_amd.encoder import WhisperEncoder
 
-    c = mg.ENCODER_CASES["tiny"]
-    x = mg.encoder_features("tiny")[:1]
+    c = signals.ENCODER_CASES["tiny"]
+    x = signals.encoder_features("tiny")[:1]
     for n_layers in (0, 1, 2):
         sd = signals.encoder_state_dict(c["d_model"], n_layers, c["ffn"], c["n_mels"], seed=c["seed"])
         ref = oracle_encoder.encoder_forward(sd, x, c["heads"], n_layers=n_layers).numpy()
@@ -82,7 +81,7 @@ def test_encoder_big_batch_uses_256_tiles_and_matches_golden(golden_dir):
     HF golden output, wherever it sits in the batch."""
     enc, sd, c = build_encoder("mid")
     g = np.load(f"{golden_dir}/encoder_mid.npz")
-    x1 = torch.from_numpy(mg.encoder_features("mid"))[:1]
+    x1 = torch.from_numpy(signals.encoder_features("mid"))[:1]
     B = 96
     x = x1.repeat(B, 1, 1).cuda()
     x[1::2] = x[1::2].flip(2)  # every other clip time-reversed: a second, different input without a second fixture
@@ -122,7 +121,7 @@ def test_encoder_errors_and_batch_independence():
     enc, sd, c = build_encoder("tiny")
     with pytest.raises(ValueError, match="length 3000"):
         enc(torch.zeros((1, 80, 2999), device="cuda"))
-    x = torch.from_numpy(mg.encoder_features("tiny")).cuda()
+    x = torch.from_numpy(signals.encoder_features("tiny")).cuda()
     y2 = enc(x)
     y1 = enc(x[1:2])
     assert torch.equal(y1[0], y2[1])  # clips are independent and the result is run-to-run identical
@@ -139,7 +138,7 @@ def test_encoder_errors_and_batch_independence():
 def build_projector(case):
     from asr_amd.projector import AudioProjector
 
-    c = mg.PROJECTOR_CASES[case]
+    c = signals.PROJECTOR_CASES[case]
     proj = AudioProjector(c["audio_dim"], c["text_dim"])
     sd = signals.projector_state_dict(c["audio_dim"], c["text_dim"], seed=c["seed"])
     proj.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
@@ -150,7 +149,7 @@ def build_projector(case):
 def test_projector_forward_backward_match_golden(golden_dir, margins, case):
     proj, sd, c = build_projector(case)
     g = np.load(f"{golden_dir}/projector_{case}.npz")
-    x, gy = mg.projector_inputs(case)
+    x, gy = signals.projector_inputs(case)
     xt = torch.from_numpy(x).cuda()
     y = proj(xt)
     assert y.dtype == torch.float32 and y.requires_grad
@@ -178,7 +177,7 @@ def test_projector_forward_backward_match_golden(golden_dir, margins, case):
 
 def test_projector_input_grad_and_inference_path_match_oracle():
     proj, sd, c = build_projector("p128")
-    x, gy = mg.projector_inputs("p128")
+    x, gy = signals.projector_inputs("p128")
     y_ref, grads = oracle_projector.projector_backward(sd, x, gy)
     xt = torch.from_numpy(x).cuda().requires_grad_(True)
     y = proj(xt)
@@ -264,7 +263,7 @@ def test_fused_encoder_projector_is_bit_identical_to_the_two_modules(enc_case, p
     enc, _, c = build_encoder(enc_case)
     proj, _, pc = build_projector(proj_case)
     assert c["d_model"] == pc["audio_dim"]
-    x = torch.from_numpy(mg.encoder_features(enc_case)).cuda()
+    x = torch.from_numpy(signals.encoder_features(enc_case)).cuda()
     with torch.no_grad():
         two = proj(enc(x))
         one = encode_and_project(enc, proj, x)
@@ -294,7 +293,7 @@ def test_fused_call_through_the_c_abi_checks_its_arguments():
     lib = _lib.load()
     enc, _, c = build_encoder("tiny")
     proj, _, pc = build_projector("p128")
-    x = torch.from_numpy(mg.encoder_features("tiny")).cuda()
+    x = torch.from_numpy(signals.encoder_features("tiny")).cuda()
     feats, handle, enc_ws = enc._prepare(x)
     B, M = feats.shape[0], feats.shape[0] * 1500
     dims = _lib.ProjectorDims(pc["audio_dim"], pc["text_dim"])
@@ -316,6 +315,21 @@ def test_fused_call_through_the_c_abi_checks_its_arguments():
     assert call(frames=2999) == _lib.ASRK_ERR_LENGTH
     assert call(ws_bytes=ws.numel() - 256) == _lib.ASRK_ERR_WORKSPACE
     assert call(enc_bytes=enc_ws.numel() // 2) == _lib.ASRK_ERR_WORKSPACE
+    # a projector whose audio_dim is not the encoder's d_model: refused before any launch (the fused tail would write
+    # [M][d_model] into a slot sized [M][audio_dim]), in the C ABI and in the Python layer
+    from asr_amd.projector import AudioProjector, encode_and_project
+    for wrong in (pc["audio_dim"] // 2, pc["audio_dim"] * 2):
+        wdims = _lib.ProjectorDims(wrong, pc["text_dim"])
+        wproj = AudioProjector(wrong, pc["text_dim"]).cuda()
+        wps = _params_struct(*[p.detach() for p in (wproj.norm.weight, wproj.linear_1.weight, wproj.linear_1.bias,
+                                                    wproj.linear_2.weight, wproj.linear_2.bias)])
+        wws = torch.empty((lib.asrk_projector_workspace_bytes(ctypes.byref(wdims), M),), dtype=torch.uint8, device="cuda")
+        rc = lib.asrk_encoder_projector_forward(handle, _lib.ptr(feats), B, 3000, _lib.ptr(None), _lib.ptr(enc_ws),
+                                                enc_ws.numel(), ctypes.byref(wdims), ctypes.byref(wps), _lib.ptr(out),
+                                                _lib.ASRK_F32, _lib.ptr(None), _lib.ptr(wws), wws.numel(), _lib.current_stream())
+        assert rc == _lib.ASRK_ERR_SHAPE
+        with pytest.raises(ValueError, match="d_model"):
+            encode_and_project(enc, wproj, x)
     hidden = torch.empty((M, pc["audio_dim"]), device="cuda")
     assert call(hidden=hidden, saved_=saved) == 0
     torch.cuda.synchronize()
@@ -326,7 +340,7 @@ def test_projector_packed_weights_follow_parameter_updates():
     """The bf16 weight copies are cached on (address, _version) of linear_1 / linear_2: an optimizer-style in-place
     update, load_state_dict and .to() must all be seen; an unchanged module must not re-pack."""
     proj, sd, c = build_projector("p128")
-    x = torch.from_numpy(mg.projector_inputs("p128")[0]).cuda()
+    x = torch.from_numpy(signals.projector_inputs("p128")[0]).cuda()
     with torch.no_grad():
         y0 = proj(x)
         buf0, key0 = proj._packed.buf, proj._packed.key
@@ -341,7 +355,7 @@ def test_projector_packed_weights_follow_parameter_updates():
         assert torch.equal(proj(x), y0)
     # the training path uses the same copies (forward W1, W2; backward their transposes): compare with a fresh module
     fresh, _, _ = build_projector("p128")
-    gy = torch.from_numpy(mg.projector_inputs("p128")[1]).cuda()
+    gy = torch.from_numpy(signals.projector_inputs("p128")[1]).cuda()
     for m in (proj, fresh):
         m.zero_grad(set_to_none=True)
         m(x).backward(gy)
@@ -351,7 +365,7 @@ def test_projector_packed_weights_follow_parameter_updates():
 
 def test_encoder_repacks_after_weight_changes():
     enc, sd, c = build_encoder("tiny")
-    x = torch.from_numpy(mg.encoder_features("tiny")).cuda()
+    x = torch.from_numpy(signals.encoder_features("tiny")).cuda()
     y0 = enc(x)
     h0 = enc._handle
     assert torch.equal(enc(x), y0) and enc._handle is h0  # steady state: the packed copy is reused

@@ -88,3 +88,17 @@ def test_generate_prompt_splice_gpu():
     assert tuple(out.shape) == (2, P - 1 + A, D) and torch.equal(out[0], ref) and torch.equal(out[1], ref)
     with pytest.raises(ValueError, match="not found in instruction"):
         build_generate_embeds(prompt, torch.zeros_like(ids), audio, chunk)
+
+
+def test_eval_wer_tool_skips_cleanly_without_weights(tmp_path):
+    """tools/eval_wer.py (row f1): with no checkpoints on disk it says so and exits 0 -- it never fetches anything."""
+    import os
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "eval_wer.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("skipped: no weights")
+    r = subprocess.run([sys.executable, tool, "--whisper-dir", str(tmp_path), "--decoder-dir", str(tmp_path),
+                        "--manifest", str(tmp_path / "m.jsonl")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "skipped: no weights" in r.stdout and "model.safetensors" in r.stdout

@@ -97,9 +97,10 @@ def test_errors_and_edge_cases(extractors):
     assert f.shape == (3, 80, 3000) and torch.all(f == -1.5)
 
 
-def test_full_size_properties(extractors):
-    """BASELINE config 2 size (256 x 30 s): properties that need no oracle run."""
-    fe = extractors[80]
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_full_size_properties(extractors, n_mels):
+    """BASELINE config 2 size (256 x 30 s, 80 and 128 mel bins): properties that need no oracle run."""
+    fe = extractors[n_mels]
     g = torch.Generator(device="cuda").manual_seed(3)
     w = (torch.randn((256, 480000), device="cuda", generator=g) * 0.1).clamp_(-1, 1)
     w[7, 100000:] = 0.0  # silence tail
@@ -109,6 +110,7 @@ def test_full_size_properties(extractors):
     mx = f.amax(dim=(1, 2))
     mn = f.amin(dim=(1, 2))
     assert torch.all(mn >= mx - 2.0 - 1e-6)  # max-8 floor in log10 units == 2.0 after /4
+    assert tuple(f.shape) == (256, n_mels, 3000)
     assert torch.all(f[7, :, 700:] == f[7, 0, 2999])  # silence tail sits on the floor
     # clip-in-batch == clip-alone, bit for bit
     assert torch.equal(fe.extract_from_device(w[5:6].clone())[0], f[5])
@@ -136,3 +138,31 @@ def test_valid_lengths_change_no_bit(extractors, n_mels):
         assert torch.equal(fe.extract_from_device(w, torch.tensor(lens, device="cuda")), full)
     with pytest.raises(ValueError):
         fe.extract_from_device(w, [1, 2])
+
+
+def test_plan_of_another_device_is_refused(extractors):
+    """asrk_logmel_f32 / asrk_logmel_f32_noalloc compare the device a plan was created on with the current one (its
+    tables are that GPU's memory).  The box has one GPU, so the test patches the plan's recorded device -- `struct
+    asrk_logmel_plan { int n_mels; int device; ... }`, asrk_logmel.hip -- and restores it."""
+    import ctypes
+
+    from asr_amd import _lib
+
+    lib = _lib.load()
+    fe = extractors[80]
+    w = torch.zeros((2, 480000), device="cuda")
+    ref = fe.extract_from_device(w)
+    plan = fe._plan(w.device)
+    dev_field = ctypes.c_int.from_address(plan.value + 4)
+    assert ctypes.c_int.from_address(plan.value).value == 80 and dev_field.value == w.device.index
+    out = torch.empty_like(ref)
+    ws = torch.empty((int(lib.asrk_logmel_workspace_bytes(2, 480000)),), dtype=torch.uint8, device="cuda")
+    dev_field.value = w.device.index + 1
+    try:
+        rc = lib.asrk_logmel_f32(plan, _lib.ptr(w), _lib.ptr(None), 2, 480000, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                 _lib.current_stream())
+        rc2 = lib.asrk_logmel_f32_noalloc(plan, _lib.ptr(w), 2, 480000, _lib.ptr(out), _lib.current_stream())
+    finally:
+        dev_field.value = w.device.index
+    assert rc == _lib.ASRK_ERR_UNSUPPORTED and rc2 == _lib.ASRK_ERR_UNSUPPORTED
+    assert torch.equal(fe.extract_from_device(w), ref)

@@ -7,7 +7,6 @@ from oracle import encoder as oe
 from oracle import logmel as ol
 from oracle import projector as op
 from tests import signals
-from tests.golden import make_golden as mg
 
 
 @pytest.mark.parametrize("n_mels", [80, 128])
@@ -45,10 +44,10 @@ def test_logmel_oracle_batch_longest_and_errors(golden_dir):
 
 @pytest.mark.parametrize("case", ["tiny", "mid", "small"])
 def test_encoder_oracle_matches_hf(golden_dir, case):
-    c = mg.ENCODER_CASES[case]
+    c = signals.ENCODER_CASES[case]
     g = np.load(f"{golden_dir}/encoder_{case}.npz")
     sd = signals.encoder_state_dict(c["d_model"], c["layers"], c["ffn"], c["n_mels"], seed=c["seed"])
-    y = oe.encoder_forward(sd, mg.encoder_features(case), c["heads"]).numpy()
+    y = oe.encoder_forward(sd, signals.encoder_features(case), c["heads"]).numpy()
     ref, mine = (g["out"], y) if "out" in g else (g["out_rows"], y[:, g["rows"], :])
     assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     with pytest.raises(ValueError):
@@ -57,10 +56,10 @@ def test_encoder_oracle_matches_hf(golden_dir, case):
 
 @pytest.mark.parametrize("case", ["p128", "p768"])
 def test_projector_oracle_matches_reference(golden_dir, case):
-    c = mg.PROJECTOR_CASES[case]
+    c = signals.PROJECTOR_CASES[case]
     g = np.load(f"{golden_dir}/projector_{case}.npz")
     sd = signals.projector_state_dict(c["audio_dim"], c["text_dim"], seed=c["seed"])
-    x, gy = mg.projector_inputs(case)
+    x, gy = signals.projector_inputs(case)
     y, grads = op.projector_backward(sd, x, gy)
     y = y.numpy()
     if "out" in g:

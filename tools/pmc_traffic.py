@@ -16,7 +16,7 @@ import sys
 # substring of the rocprof kernel name -> key.  The log-mel front-end is one logical launch: its bytes are summed over
 # all its kernels and divided by the launches of the tile kernel alone (COUNT_ONLY).
 FAMILIES = {"gemm256p_kernel": "gemm256p_kernel", "gemm256_kernel": "gemm256_kernel", "gemm_bf16_kernel": "gemm_bf16_kernel",
-            "attention_kernel": "attention_kernel", "layernorm_kernel": "layernorm_kernel", "logmel": "logmel_kernel"}
+            "attention_kernel": "attention_kernel", "layernorm_kernel": "layernorm_kernel", "logmel": "logmel_tile_kernel+logmel_finish_kernel"}
 NOT_A_LAUNCH = ("logmel_finish_kernel",)
 
 
