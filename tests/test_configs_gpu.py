@@ -76,6 +76,7 @@ def build_projector(audio_dim, text_dim, seed):
 
 
 # ------------------------------------------------------------------------------------------------ configs[3]
+@pytest.mark.timeout(600)
 def test_large_v3_full_depth_batch16_forward_and_train_step(margins):
     from asr_amd.distributed import FlatGradAllReducer
     from asr_amd.encoder import WhisperEncoder
@@ -143,6 +144,7 @@ def test_large_v3_full_depth_batch16_forward_and_train_step(margins):
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]
+@pytest.mark.timeout(300)
 def test_ragged_batch64_collate_encoder_projector(margins):
     from asr_amd import LogMelFeatureExtractor
     from asr_amd.collate import device_collate
