@@ -18,6 +18,20 @@
 
 #include <type_traits>
 
+// The wave's issue priority is raised while it feeds the matrix pipe: four waves of four workgroups share a SIMD, and
+// by age alone the one that is multiplying gets the issue slots the three in their softmax leave over (round 3, A/B twice
+// on one box: attention 5.998 -> 5.91 ms per pipeline-small step with priority 1, the same with 2).
+#ifndef ASRK_ATTN_PRIO
+#define ASRK_ATTN_PRIO 1
+#endif
+#if ASRK_ATTN_PRIO > 0
+#define ATTN_PRIO_MFMA() __builtin_amdgcn_s_setprio(ASRK_ATTN_PRIO)
+#define ATTN_PRIO_VALU() __builtin_amdgcn_s_setprio(0)
+#else
+#define ATTN_PRIO_MFMA() do { } while (0)
+#define ATTN_PRIO_VALU() do { } while (0)
+#endif
+
 namespace {
 
 constexpr int HD = 64;       // head_dim (Whisper: always 64)
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         vo[i] = (uint32_t)(row * ldb + (2 * d + (slot ^ (((row >> 1) & 1) << 2)) * 8) * 2);  // V image: chunk ^ (((row >> 1) & 1) << 2)
     }
     const int64_t tile_step = (int64_t)KT * ldb;  // bytes
-    auto stage = [&](int kt, int buf) {
+    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
         char* kb = smem + buf * (2 * TILE_B);
         char* vb = kb + TILE_B;
         const char* tb = uniform_ptr(reinterpret_cast<const char*>(base) + kt * tile_step);
@@ -127,79 +141,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     const int nkt = (T + KT - 1) / KT;
     stage(0, 0);
-    // MASKED (compile time) marks the ragged last tile: a run-time test inside one loop body is turned
-    // into 31 v_cndmask per tile by if-conversion
-    auto tile = [&](int kt, auto masked_c) {
-        constexpr bool MASKED = decltype(masked_c)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
-        const char* kb = smem + (kt & 1) * (2 * TILE_B);
-        const char* vb = kb + TILE_B;
+    const bool wave_active = q0 < T;  // the last query block of a clip may have waves without a single query (T = 1500: one of 48)
 
-        // ---- S^T[mt] = K[32 mt .. +31][:] . Q^T   (keys on rows/registers, queries on lanes)
-        f32x16 sacc[2];
+    // ---- S^T[mt] = K[32 mt .. +31][:] . Q^T   (keys on rows/registers, queries on lanes).  LOG2Q: the chains start
+    // from -ref (negm is the C operand of each chain's first MFMA, never copied).  MASKED: keys past the clip's end -> -inf
+    auto scores = [&](const char* kb, int kt, f32x16 (&sacc)[2], auto nmt_c, auto masked_c, auto ref_c) __attribute__((always_inline)) {
+        constexpr int NMT = decltype(nmt_c)::value;
+        constexpr bool MASKED = decltype(masked_c)::value;
+        constexpr bool FROM_REF = decltype(ref_c)::value;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            if (LOG2Q) {
-                sacc[mt] = negm;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[mt][i] = 0.f;
-            }
+        for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + mt * 4096 + k_row_off + (((2 * s + hh) ^ k_sw) << 4));
-                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[mt], 0, 0, 0);
+                if (s == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                    sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], FROM_REF ? negm : z, 0, 0, 0);
+                } else {
+                    sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[mt], 0, 0, 0);
+                }
             }
         }
-        if (MASKED) {  // mask keys past the end of the clip
+        if (MASKED) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kt * KT + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
                     if (kv >= T) sacc[mt][r] = -INFINITY;
                 }
         }
-        // ---- online softmax for this lane's query
+    };
+    // ---- the exponentials of a tile against the current reference: p -> bf16 B operands of the PV products, row sum
+    auto exps = [&](f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& psum, auto nmt_c) __attribute__((always_inline)) {
+        constexpr int NMT = decltype(nmt_c)::value;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sacc[mt][r]);  // bare v_exp_f32: exp2f() adds a denormal rescale (5 VALU)
+                psum += p;
+                pf[mt][r >> 3][r & 7] = (bf16_t)p;
+            }
+    };
+    // ---- LOG2Q, the eager form: tile maximum, reference move when it exceeds the reference by more than THR2 (always
+    // on the first tile), exponentials.  Lazy rescale: until then p may reach 2^THR2 (harmless: bf16 has fp32's exponent
+    // range and a relative rounding error that does not depend on the magnitude) and the 32 accumulator multiplies are
+    // skipped for the whole wave.  softmax is invariant to the reference.
+    auto softmax_eager_log2 = [&](f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& psum, bool first, auto nmt_c) __attribute__((always_inline)) {
+        constexpr int NMT = decltype(nmt_c)::value;
         float mx = sacc[0][0];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // Lazy rescale: the running reference only moves when the tile's maximum exceeds it by more than
-        // RESCALE_THR; until then p may reach e^THR (harmless in fp32 / bf16, whose exponent range is fp32's)
-        // and the 32 accumulator multiplies are skipped for the whole wave.  softmax is invariant to the
-        // reference, so the result differs from eager rescaling only in rounding.
+        constexpr float THR2 = 8.0f;
+        const bool moved = first || mx > THR2;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // wave-uniform
+            const float dlt = moved ? mx : 0.f;
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dlt);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[mt][i] -= dlt;
+            nref -= dlt;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) negm[i] = nref;
+        }
+        exps(sacc, pf, psum, nmt_c);
+    };
+
+    // MASKED (compile time) marks the ragged last tile: a run-time test inside one loop body is turned into 31 v_cndmask
+    // per tile by if-conversion.  NMT = 1: a last tile with at most 32 keys multiplies only its first half.
+    // FAST (LOG2Q only): no tile maximum and no reference at all -- p = 2^s as the scores stand (log2 units).  softmax is
+    // invariant to the reference; all the reference has to do is keep 2^(s - ref) inside fp32's exponent range, and
+    // bf16 operands / fp32 accumulators hold p = 2^40 with the same RELATIVE accuracy as p <= 1.  So the loop runs
+    // without the 20 max instructions, the half-wave exchange, the accumulator block that held -ref (and the 16 moves
+    // that copied it every tile): it is bound by vector-ALU cycles (profiles/r3_attn_base_sq_counters.txt: VALU busy
+    // 78 % of a SIMD's time, matrix pipe 54 %).  The guard comes once, after the loop: a query whose row sum is not in
+    // [2^-100, 2^100), or whose accumulators are not finite, had scores this shortcut cannot hold (|row maximum| beyond
+    // ~100 log2 units: never seen on LayerNorm-ed activations, forced in tests/test_kernels_gpu.py); the workgroup
+    // votes and, if any lane failed, runs the whole key loop again in the eager form, whose reference follows the
+    // running maximum.  Contributions below 2^-126 are flushed, i.e. keys more than 2^-26 below the row's sum.
+    auto tile = [&](int kt, auto masked_c, auto nmt_c, auto fast_c) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+        constexpr int NMT = decltype(nmt_c)::value;
+        constexpr bool FAST = decltype(fast_c)::value && LOG2Q;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        if (!wave_active) return;  // (wave-uniform) staging and barriers only
+        const char* kb = smem + (kt & 1) * (2 * TILE_B);
+        const char* vb = kb + TILE_B;
+
+        ATTN_PRIO_MFMA();
+        f32x16 sacc[2];
+        scores(kb, kt, sacc, nmt_c, masked_c, std::integral_constant<bool, LOG2Q && !FAST>{});
+        ATTN_PRIO_VALU();
         float psum = 0.f;
         bf16x8 pf[2][2];  // [mt][k-step s]: registers 8 s .. 8 s + 7
         if (LOG2Q) {
-            // sacc already holds s - ref (log2 units); the first tile always sets the reference to its maximum
-            constexpr float THR2 = 8.0f;
-            const bool moved = kt == 0 || mx > THR2;
-            if (__builtin_amdgcn_ballot_w64(moved) != 0) {  // wave-uniform
-                const float dlt = moved ? mx : 0.f;
-                const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-dlt);
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { sacc[0][i] -= dlt; sacc[1][i] -= dlt; }
-                nref -= dlt;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) negm[i] = nref;
+            if (FAST) {
+                exps(sacc, pf, psum, nmt_c);  // p = 2^s, reference 0: see below
+            } else {
+                softmax_eager_log2(sacc, pf, psum, kt == 0, nmt_c);
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[mt][r]);
-                    psum += p;
-                    pf[mt][r >> 3][r & 7] = (bf16_t)p;
-                }
         } else {
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[mt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             constexpr float RESCALE_THR = 5.5f;
             const bool moved = mx > m_run + RESCALE_THR;
             const float m_new = moved ? mx : m_run;
@@ -211,10 +270,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
             }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    // bare v_exp_f32: exp2f() adds a denormal-range rescale (5 VALU) per call
                     const float p = __builtin_amdgcn_exp2f(fmaf(sacc[mt][r], LOG2E, -mb));
                     psum += p;
                     pf[mt][r >> 3][r & 7] = (bf16_t)p;
@@ -224,8 +282,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         l_run += psum;
 
         // ---- O^T[ht] += V^T[32 ht ..][keys] . P^T   (k order inside a step: 8 (j >> 2) + 4 hh + (j & 3))
+        ATTN_PRIO_MFMA();
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -241,10 +300,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                     o[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[mt][s], o[ht], 0, 0, 0);
                 }
+        ATTN_PRIO_VALU();
     };
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
     const int nfull = (T % KT) != 0 ? nkt - 1 : nkt;
-    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
-    if (nfull < nkt) tile(nkt - 1, std::true_type{});
+    auto run = [&](auto fast_c) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_c)::value && LOG2Q;
+        if (nfull > 0) {
+            if (FAST) tile(0, std::false_type{}, C2{}, std::true_type{});
+            else tile(0, std::false_type{}, C2{}, std::false_type{});  // eager: the first tile sets the reference
+        }
+        for (int kt = 1; kt < nfull; ++kt) tile(kt, std::false_type{}, C2{}, fast_c);
+        if (nfull < nkt) {
+            if (T - nfull * KT <= 32) tile(nkt - 1, std::true_type{}, C1{}, fast_c);
+            else tile(nkt - 1, std::true_type{}, C2{}, fast_c);
+        }
+    };
+    run(std::true_type{});
+    if (LOG2Q) {
+        const float l_chk = l_run + __shfl_xor(l_run, 32, 64);
+        float fin = 0.f;  // 0 * x is NaN for x = inf / NaN
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fin = fmaf(o[0][i], 0.f, fmaf(o[1][i], 0.f, fin));
+        const bool bad = wave_active && !(l_chk < 1.2676506e30f && l_chk >= 7.8886091e-31f && fin == 0.f);  // 2^100, 2^-100
+        if (__syncthreads_or(bad ? 1 : 0)) {  // rare: once more, with the reference following the maximum
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
+            l_run = 0.f;
+            nref = 0.f;
+            stage(0, 0);
+            run(std::false_type{});
+        }
+    }
 
     // ---- normalise and store: lane holds O[q][32 ht + (r & 3) + 8 (r >> 2) + 4 hh]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -237,6 +237,51 @@ def test_attention_log2_domain(lib, scale, shift):
     assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("case", ["late_spike", "all_far_negative", "ordinary", "inf_free_tail"])
+def test_attention_log2_reference_free_path_and_its_fallback(lib, case):
+    """The encoder's attention (log2 domain) takes p = 2^s WITHOUT a reference and checks after the key loop that every
+    row sum stayed inside [2^-100, 2^100) and the accumulators are finite; otherwise the workgroup repeats the loop in
+    the eager form.  `late_spike`: one key in the 5th tile scores ~ +370 log2 units for one query (the shortcut
+    overflows to inf -> fallback).  `all_far_negative`: every score of one query is ~ -290 (row sum underflows ->
+    fallback).  `ordinary`: |s| of a few units, the shortcut's result stands.  `inf_free_tail`: T = 1500 whose last
+    tile holds 28 keys (the half-tile instance).  Reference: float64 softmax."""
+    T, H = (1500, 2) if case == "inf_free_tail" else (384, 1)
+    d = 64 * H
+    g = torch.Generator(device="cuda").manual_seed(17)
+    q = torch.randn((T, d), device="cuda", generator=g) * 0.4
+    k = torch.randn((T, d), device="cuda", generator=g)
+    v = torch.randn((T, d), device="cuda", generator=g)
+    if case == "late_spike":
+        q[7, :64] = 2.0
+        k[300, :64] = 2.0        # score 256 natural units = 369 log2 units, in tile 4
+    if case == "all_far_negative":
+        k[:, :64] = k[:, :64] * 0.05 + 1.0
+        q[9, :64] = -3.125       # every score ~ -200 natural units
+    LOG2E = 1.4426950408889634
+    qkv = torch.cat([q * LOG2E, k, v], dim=1).to(torch.bfloat16)
+    out = torch.full((T, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    assert lib.asrk_attention_log2_bf16(_p(qkv), _p(out), 1, T, H, _stream()) == 0
+    torch.cuda.synchronize()
+    f = qkv.double()
+    qd = (f[:, :d] / LOG2E).view(T, H, 64).transpose(0, 1)
+    kd = f[:, d:2 * d].view(T, H, 64).transpose(0, 1)
+    vd = f[:, 2 * d:].view(T, H, 64).transpose(0, 1)
+    sc = qd @ kd.transpose(-1, -2)
+    ref = (torch.softmax(sc, dim=-1) @ vd).transpose(0, 1).reshape(T, d)
+    if case == "late_spike":
+        assert sc[0, 7].max().item() > 200 and sc[0, 7].argmax().item() == 300
+    if case == "all_far_negative":
+        assert sc[0, 9].max().item() < -150
+    assert torch.isfinite(out.float()).all()
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+    # the same call again gives the same bits (the fallback leaves no state behind)
+    out2 = torch.empty_like(out)
+    assert lib.asrk_attention_log2_bf16(_p(qkv), _p(out2), 1, T, H, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
 def test_attention_online_softmax_rescale(lib):
     """Force the running-max rescale: one key, late in the sequence, dominates one query."""
     B, T, H = 1, 320, 1
