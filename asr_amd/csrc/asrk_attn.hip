@@ -21,6 +21,12 @@
 // The wave's issue priority is raised while it feeds the matrix pipe: four waves of four workgroups share a SIMD, and
 // by age alone the one that is multiplying gets the issue slots the three in their softmax leave over (round 3, A/B twice
 // on one box: attention 5.998 -> 5.91 ms per pipeline-small step with priority 1, the same with 2).
+#ifndef ASRK_ATTN_PREFETCH
+#define ASRK_ATTN_PREFETCH 0
+#endif
+#ifndef ASRK_ATTN_PSUM_MFMA  // experiment (slower): row sums on the matrix pipe
+#define ASRK_ATTN_PSUM_MFMA 0
+#endif
 #ifndef ASRK_ATTN_PRIO
 #define ASRK_ATTN_PRIO 1
 #endif
@@ -30,6 +36,16 @@
 #else
 #define ATTN_PRIO_MFMA() do { } while (0)
 #define ATTN_PRIO_VALU() do { } while (0)
+#endif
+
+#ifdef ASRK_ATTN_STAMPS  // diagnostic build only (tools/attn_stamps.py): s_memtime sums per phase of the key loop
+__device__ unsigned long long g_attn_stamps[1024 * 8];
+extern "C" int asrk_debug_read_attn_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#define ASTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
 #endif
 
 namespace {
@@ -97,16 +113,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         ko[i] = (uint32_t)(row * ldb + (d + (slot ^ ((row >> 1) & 7)) * 8) * 2);            // K image: chunk ^ ((row >> 1) & 7)
         vo[i] = (uint32_t)(row * ldb + (2 * d + (slot ^ (((row >> 1) & 1) << 2)) * 8) * 2);  // V image: chunk ^ (((row >> 1) & 1) << 2)
     }
-    const int64_t tile_step = (int64_t)KT * ldb;  // bytes
+    // The DMA reads through a buffer descriptor of this (clip, head)'s rows: the tile's start is the instruction's scalar
+    // offset and the lane's chunk its 32-bit vector offset, so no vector address arithmetic runs per tile.
+    const int tile_step = KT * ldb;  // bytes; (T / KT + 1) * tile_step < 2^31 is checked by the launcher
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(base), 0, T * ldb - head * HD * 2, 0x00020000);
+    auto dma16 = [&](uint32_t voff, int soff, char* lds) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds), 16, voff, soff, 0, 0);
+    };
     auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
         char* kb = smem + buf * (2 * TILE_B);
         char* vb = kb + TILE_B;
-        const char* tb = uniform_ptr(reinterpret_cast<const char*>(base) + kt * tile_step);
+        const int soff = kt * tile_step;
         if ((kt + 1) * KT <= T) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                glds16(tb + ko[i], kb + i * 4096 + wave_lds);
-                glds16(tb + vo[i], vb + i * 4096 + wave_lds);
+                dma16(ko[i], soff, kb + i * 4096 + wave_lds);
+                dma16(vo[i], soff, vb + i * 4096 + wave_lds);
             }
         } else {
             const int last = T - 1 - kt * KT;  // last valid row of this tile
@@ -114,8 +137,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int i = 0; i < 2; ++i) {
                 const int row = srow + 32 * i;
                 const uint32_t back = (uint32_t)((row > last ? row - last : 0) * ldb);  // rows past the end read the last key
-                glds16(tb + (ko[i] - back), kb + i * 4096 + wave_lds);
-                glds16(tb + (vo[i] - back), vb + i * 4096 + wave_lds);
+                dma16(ko[i] - back, soff, kb + i * 4096 + wave_lds);
+                dma16(vo[i] - back, soff, vb + i * 4096 + wave_lds);
             }
         }
     };
@@ -139,6 +162,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // V^T (A operand of PV) through the transposing read: group g = (lane >> 4) & 1, i = lane & 15
     const int vi = lane & 15, vg = (lane >> 4) & 1;
 
+#ifdef ASRK_ATTN_STAMPS
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     const int nkt = (T + KT - 1) / KT;
     stage(0, 0);
     const bool wave_active = q0 < T;  // the last query block of a clip may have waves without a single query (T = 1500: one of 48)
@@ -149,6 +176,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         constexpr int NMT = decltype(nmt_c)::value;
         constexpr bool MASKED = decltype(masked_c)::value;
         constexpr bool FROM_REF = decltype(ref_c)::value;
+#if ASRK_ATTN_PREFETCH  // experiment (slower): fragments one MFMA ahead
+        // K fragments one MFMA ahead (two register sets), so that a fragment's LDS round trip runs under the previous MFMA
+        auto kfrag = [&](int i) __attribute__((always_inline)) {
+            const int mt = i >> 2, s = i & 3;
+            return *reinterpret_cast<const bf16x8*>(kb + mt * 4096 + k_row_off + (((2 * s + hh) ^ k_sw) << 4));
+        };
+        bf16x8 kf[2];
+        kf[0] = kfrag(0);
+#pragma unroll
+        for (int i = 0; i < 4 * NMT; ++i) {
+            const int mt = i >> 2, s = i & 3;
+            if (i + 1 < 4 * NMT) kf[(i + 1) & 1] = kfrag(i + 1);
+            if (s == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) z[j] = 0.f;
+                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 1], qf[0], FROM_REF ? negm : z, 0, 0, 0);
+            } else {
+                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 1], qf[s], sacc[mt], 0, 0, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
@@ -164,6 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         }
+#endif
         if (MASKED) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
@@ -174,9 +224,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
         }
     };
-    // ---- the exponentials of a tile against the current reference: p -> bf16 B operands of the PV products, row sum
-    auto exps = [&](f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& psum, auto nmt_c) __attribute__((always_inline)) {
+    // ---- the exponentials of a tile against the current reference: p -> bf16 B operands of the PV products, row sum.
+    // SUM_MFMA (the fast path): the row sum moves to the matrix pipe.  v_mfma_f32_4x4x4_16b_bf16 multiplies sixteen
+    // independent 4 x 4 blocks; lane l supplies column l & 3 of block l >> 2 of B (four k values) and receives the same
+    // column of D, so with A = ones every lane gets the sum of ITS OWN four bf16 values: 8 of these (8 cycles each) add
+    // a lane's 32 probabilities in place of 32 v_add_f32 on the vector ALU that bounds this loop.  The sum is then taken
+    // over the bf16-rounded p, the values the PV products use.
+    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
+    auto exps = [&](f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& psum, auto nmt_c, auto sum_mfma_c) __attribute__((always_inline)) {
         constexpr int NMT = decltype(nmt_c)::value;
+        constexpr bool SUM_MFMA = decltype(sum_mfma_c)::value;
+        if (SUM_MFMA) {
+            typedef short short4s __attribute__((ext_vector_type(4)));
+            const short4s ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t w[4];  // packed once (v_cvt_pk_bf16_f32); the same words feed the PV product and the row sum
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x2 t;
+                        t[0] = (bf16_t)__builtin_amdgcn_exp2f(sacc[mt][8 * h + 2 * j]);
+                        t[1] = (bf16_t)__builtin_amdgcn_exp2f(sacc[mt][8 * h + 2 * j + 1]);
+                        w[j] = __builtin_bit_cast(uint32_t, t);
+                    }
+                    pf[mt][h] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+                    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(short4s, u32x2{w[0], w[1]}), lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(short4s, u32x2{w[2], w[3]}), lacc, 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -214,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int i = 0; i < 16; ++i) negm[i] = nref;
         }
-        exps(sacc, pf, psum, nmt_c);
+        exps(sacc, pf, psum, nmt_c, std::false_type{});
     };
 
     // MASKED (compile time) marks the ragged last tile: a run-time test inside one loop body is turned into 31 v_cndmask
@@ -229,26 +307,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // ~100 log2 units: never seen on LayerNorm-ed activations, forced in tests/test_kernels_gpu.py); the workgroup
     // votes and, if any lane failed, runs the whole key loop again in the eager form, whose reference follows the
     // running maximum.  Contributions below 2^-126 are flushed, i.e. keys more than 2^-26 below the row's sum.
-    auto tile = [&](int kt, auto masked_c, auto nmt_c, auto fast_c) __attribute__((always_inline)) {
+    auto tile = [&](int kt, auto masked_c, auto nmt_c, auto fast_c, auto buf_c) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_c)::value;  // LDS buffer of tile kt = kt & 1: a constant, so that fragment addresses are immediates
         constexpr bool MASKED = decltype(masked_c)::value;
         constexpr int NMT = decltype(nmt_c)::value;
         constexpr bool FAST = decltype(fast_c)::value && LOG2Q;
+        ASTAMP(5);  // loop overhead / whatever lies between two tiles
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        ASTAMP(0);  // wait for the tile's DMA + barrier
+        if (kt + 1 < nkt) stage(kt + 1, BUF ^ 1);
+        ASTAMP(1);  // DMA issue
         if (!wave_active) return;  // (wave-uniform) staging and barriers only
-        const char* kb = smem + (kt & 1) * (2 * TILE_B);
+        const char* kb = smem + BUF * (2 * TILE_B);
         const char* vb = kb + TILE_B;
 
         ATTN_PRIO_MFMA();
         f32x16 sacc[2];
         scores(kb, kt, sacc, nmt_c, masked_c, std::integral_constant<bool, LOG2Q && !FAST>{});
         ATTN_PRIO_VALU();
+        ASTAMP(2);  // QK^T: fragment reads + 8 MFMAs issued
         float psum = 0.f;
         bf16x8 pf[2][2];  // [mt][k-step s]: registers 8 s .. 8 s + 7
         if (LOG2Q) {
             if (FAST) {
-                exps(sacc, pf, psum, nmt_c);  // p = 2^s, reference 0: see below
+                exps(sacc, pf, psum, nmt_c, std::integral_constant<bool, ASRK_ATTN_PSUM_MFMA != 0>{});  // p = 2^s, reference 0: see below
             } else {
                 softmax_eager_log2(sacc, pf, psum, kt == 0, nmt_c);
             }
@@ -280,9 +363,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             m_run = m_new;
         }
         l_run += psum;
+        ASTAMP(3);  // softmax (includes waiting for the score MFMAs)
 
         // ---- O^T[ht] += V^T[32 ht ..][keys] . P^T   (k order inside a step: 8 (j >> 2) + 4 hh + (j & 3))
         ATTN_PRIO_MFMA();
+#if ASRK_ATTN_PREFETCH
+        auto vfrag = [&](int i) __attribute__((always_inline)) {  // i = (mt, s, ht)
+            const int mt = i >> 2, s = (i >> 1) & 1, ht = i & 1;
+            bf16x8 vf;
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int row = 32 * mt + 16 * s + 4 * hh + 8 * rd + (vi >> 2);
+                const int chunk = 4 * ht + 2 * vg + ((vi & 3) >> 1);
+                const int off = row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) + (vi & 1) * 8;
+                const bf16x4 t = lds_read_tr16(vb + off);
+                vf[4 * rd + 0] = t[0]; vf[4 * rd + 1] = t[1]; vf[4 * rd + 2] = t[2]; vf[4 * rd + 3] = t[3];
+            }
+            return vf;
+        };
+        bf16x8 vfr[2];
+        vfr[0] = vfrag(0);
+#pragma unroll
+        for (int i = 0; i < 4 * NMT; ++i) {
+            const int mt = i >> 2, s = (i >> 1) & 1, ht = i & 1;
+            if (i + 1 < 4 * NMT) vfr[(i + 1) & 1] = vfrag(i + 1);
+            o[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i & 1], pf[mt][s], o[ht], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -300,31 +407,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                     o[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[mt][s], o[ht], 0, 0, 0);
                 }
+#endif
         ATTN_PRIO_VALU();
+        ASTAMP(4);  // PV: transposing reads + 8 MFMAs issued
     };
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
     const int nfull = (T % KT) != 0 ? nkt - 1 : nkt;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
     auto run = [&](auto fast_c) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_c)::value && LOG2Q;
+        int kt = 0;
         if (nfull > 0) {
-            if (FAST) tile(0, std::false_type{}, C2{}, std::true_type{});
-            else tile(0, std::false_type{}, C2{}, std::false_type{});  // eager: the first tile sets the reference
+            if (FAST) tile(0, std::false_type{}, C2{}, std::true_type{}, B0{});
+            else tile(0, std::false_type{}, C2{}, std::false_type{}, B0{});  // eager: the first tile sets the reference
+            kt = 1;
         }
-        for (int kt = 1; kt < nfull; ++kt) tile(kt, std::false_type{}, C2{}, fast_c);
-        if (nfull < nkt) {
-            if (T - nfull * KT <= 32) tile(nkt - 1, std::true_type{}, C1{}, fast_c);
-            else tile(nkt - 1, std::true_type{}, C2{}, fast_c);
+        for (; kt + 1 < nfull; kt += 2) {  // kt is odd here
+            tile(kt, std::false_type{}, C2{}, fast_c, B1{});
+            tile(kt + 1, std::false_type{}, C2{}, fast_c, B0{});
+        }
+        if (kt < nfull) { tile(kt, std::false_type{}, C2{}, fast_c, B1{}); ++kt; }
+        if (nfull < nkt) {  // kt == nfull == nkt - 1
+            const bool half = T - nfull * KT <= 32;
+            if (kt & 1) {
+                if (half) tile(kt, std::true_type{}, C1{}, fast_c, B1{});
+                else tile(kt, std::true_type{}, C2{}, fast_c, B1{});
+            } else {
+                if (half) tile(kt, std::true_type{}, C1{}, fast_c, B0{});
+                else tile(kt, std::true_type{}, C2{}, fast_c, B0{});
+            }
         }
     };
     run(std::true_type{});
     if (LOG2Q) {
+        l_run += lacc[0];  // (zero unless the fast path summed on the matrix pipe)
         const float l_chk = l_run + __shfl_xor(l_run, 32, 64);
         float fin = 0.f;  // 0 * x is NaN for x = inf / NaN
 #pragma unroll
         for (int i = 0; i < 16; ++i) fin = fmaf(o[0][i], 0.f, fmaf(o[1][i], 0.f, fin));
         const bool bad = wave_active && !(l_chk < 1.2676506e30f && l_chk >= 7.8886091e-31f && fin == 0.f);  // 2^100, 2^-100
-        if (__syncthreads_or(bad ? 1 : 0)) {  // rare: once more, with the reference following the maximum
+        if (__builtin_expect(__syncthreads_or(bad ? 1 : 0), 0)) {  // rare: once more, with the reference following the maximum
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
             l_run = 0.f;
@@ -334,6 +458,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
 
+#ifdef ASRK_ATTN_STAMPS
+    if (lane == 0 && blockIdx.x < 1024 && wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g_attn_stamps[blockIdx.x * 8 + i] = st_sum[i];
+        g_attn_stamps[blockIdx.x * 8 + 6] = nkt;
+    }
+#endif
     // ---- normalise and store: lane holds O[q][32 ht + (r & 3) + 8 (r >> 2) + 4 hh]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -363,6 +494,7 @@ int asrk_launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int H, b
     const long n_pairs = (long)B * H;
     const long blocks = 8 * ((n_pairs + 7) / 8) * ((T + QT - 1) / QT);
     if (blocks > 0x7fffffffL) return ASRK_ERR_SHAPE;
+    if ((long)(T + KT) * 3 * H * HD * 2 >= (1L << 31)) return ASRK_ERR_SHAPE;  // 32-bit byte offsets inside one clip's q | k | v rows
     if (q_log2e)
         hipLaunchKernelGGL(attention_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, qkv, out, T, H, (int)n_pairs);
     else
