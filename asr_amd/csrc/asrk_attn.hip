@@ -21,12 +21,6 @@
 // The wave's issue priority is raised while it feeds the matrix pipe: four waves of four workgroups share a SIMD, and
 // by age alone the one that is multiplying gets the issue slots the three in their softmax leave over (round 3, A/B twice
 // on one box: attention 5.998 -> 5.91 ms per pipeline-small step with priority 1, the same with 2).
-#ifndef ASRK_ATTN_PREFETCH
-#define ASRK_ATTN_PREFETCH 0
-#endif
-#ifndef ASRK_ATTN_PSUM_MFMA  // experiment (slower): row sums on the matrix pipe
-#define ASRK_ATTN_PSUM_MFMA 0
-#endif
 #ifndef ASRK_ATTN_PRIO
 #define ASRK_ATTN_PRIO 1
 #endif
@@ -176,28 +170,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         constexpr int NMT = decltype(nmt_c)::value;
         constexpr bool MASKED = decltype(masked_c)::value;
         constexpr bool FROM_REF = decltype(ref_c)::value;
-#if ASRK_ATTN_PREFETCH  // experiment (slower): fragments one MFMA ahead
-        // K fragments one MFMA ahead (two register sets), so that a fragment's LDS round trip runs under the previous MFMA
-        auto kfrag = [&](int i) __attribute__((always_inline)) {
-            const int mt = i >> 2, s = i & 3;
-            return *reinterpret_cast<const bf16x8*>(kb + mt * 4096 + k_row_off + (((2 * s + hh) ^ k_sw) << 4));
-        };
-        bf16x8 kf[2];
-        kf[0] = kfrag(0);
-#pragma unroll
-        for (int i = 0; i < 4 * NMT; ++i) {
-            const int mt = i >> 2, s = i & 3;
-            if (i + 1 < 4 * NMT) kf[(i + 1) & 1] = kfrag(i + 1);
-            if (s == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) z[j] = 0.f;
-                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 1], qf[0], FROM_REF ? negm : z, 0, 0, 0);
-            } else {
-                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 1], qf[s], sacc[mt], 0, 0, 0);
-            }
-        }
-#else
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
@@ -213,7 +185,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         }
-#endif
         if (MASKED) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt)
@@ -224,37 +195,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
         }
     };
-    // ---- the exponentials of a tile against the current reference: p -> bf16 B operands of the PV products, row sum.
-    // SUM_MFMA (the fast path): the row sum moves to the matrix pipe.  v_mfma_f32_4x4x4_16b_bf16 multiplies sixteen
-    // independent 4 x 4 blocks; lane l supplies column l & 3 of block l >> 2 of B (four k values) and receives the same
-    // column of D, so with A = ones every lane gets the sum of ITS OWN four bf16 values: 8 of these (8 cycles each) add
-    // a lane's 32 probabilities in place of 32 v_add_f32 on the vector ALU that bounds this loop.  The sum is then taken
-    // over the bf16-rounded p, the values the PV products use.
-    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-    auto exps = [&](f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& psum, auto nmt_c, auto sum_mfma_c) __attribute__((always_inline)) {
+    // ---- the exponentials of a tile against the current reference: p -> bf16 B operands of the PV products, row sum
+    auto exps = [&](f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& psum, auto nmt_c) __attribute__((always_inline)) {
         constexpr int NMT = decltype(nmt_c)::value;
-        constexpr bool SUM_MFMA = decltype(sum_mfma_c)::value;
-        if (SUM_MFMA) {
-            typedef short short4s __attribute__((ext_vector_type(4)));
-            const short4s ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    uint32_t w[4];  // packed once (v_cvt_pk_bf16_f32); the same words feed the PV product and the row sum
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bf16x2 t;
-                        t[0] = (bf16_t)__builtin_amdgcn_exp2f(sacc[mt][8 * h + 2 * j]);
-                        t[1] = (bf16_t)__builtin_amdgcn_exp2f(sacc[mt][8 * h + 2 * j + 1]);
-                        w[j] = __builtin_bit_cast(uint32_t, t);
-                    }
-                    pf[mt][h] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
-                    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(short4s, u32x2{w[0], w[1]}), lacc, 0, 0, 0);
-                    lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(short4s, u32x2{w[2], w[3]}), lacc, 0, 0, 0);
-                }
-            return;
-        }
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -292,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int i = 0; i < 16; ++i) negm[i] = nref;
         }
-        exps(sacc, pf, psum, nmt_c, std::false_type{});
+        exps(sacc, pf, psum, nmt_c);
     };
 
     // MASKED (compile time) marks the ragged last tile: a run-time test inside one loop body is turned into 31 v_cndmask
@@ -331,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         bf16x8 pf[2][2];  // [mt][k-step s]: registers 8 s .. 8 s + 7
         if (LOG2Q) {
             if (FAST) {
-                exps(sacc, pf, psum, nmt_c, std::integral_constant<bool, ASRK_ATTN_PSUM_MFMA != 0>{});  // p = 2^s, reference 0: see below
+                exps(sacc, pf, psum, nmt_c);  // p = 2^s, reference 0: see below
             } else {
                 softmax_eager_log2(sacc, pf, psum, kt == 0, nmt_c);
             }
@@ -367,29 +310,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
         // ---- O^T[ht] += V^T[32 ht ..][keys] . P^T   (k order inside a step: 8 (j >> 2) + 4 hh + (j & 3))
         ATTN_PRIO_MFMA();
-#if ASRK_ATTN_PREFETCH
-        auto vfrag = [&](int i) __attribute__((always_inline)) {  // i = (mt, s, ht)
-            const int mt = i >> 2, s = (i >> 1) & 1, ht = i & 1;
-            bf16x8 vf;
-#pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const int row = 32 * mt + 16 * s + 4 * hh + 8 * rd + (vi >> 2);
-                const int chunk = 4 * ht + 2 * vg + ((vi & 3) >> 1);
-                const int off = row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) + (vi & 1) * 8;
-                const bf16x4 t = lds_read_tr16(vb + off);
-                vf[4 * rd + 0] = t[0]; vf[4 * rd + 1] = t[1]; vf[4 * rd + 2] = t[2]; vf[4 * rd + 3] = t[3];
-            }
-            return vf;
-        };
-        bf16x8 vfr[2];
-        vfr[0] = vfrag(0);
-#pragma unroll
-        for (int i = 0; i < 4 * NMT; ++i) {
-            const int mt = i >> 2, s = (i >> 1) & 1, ht = i & 1;
-            if (i + 1 < 4 * NMT) vfr[(i + 1) & 1] = vfrag(i + 1);
-            o[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i & 1], pf[mt][s], o[ht], 0, 0, 0);
-        }
-#else
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -407,7 +327,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                     o[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[mt][s], o[ht], 0, 0, 0);
                 }
-#endif
         ATTN_PRIO_VALU();
         ASTAMP(4);  // PV: transposing reads + 8 MFMAs issued
     };
@@ -442,7 +361,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     run(std::true_type{});
     if (LOG2Q) {
-        l_run += lacc[0];  // (zero unless the fast path summed on the matrix pipe)
         const float l_chk = l_run + __shfl_xor(l_run, 32, 64);
         float fin = 0.f;  // 0 * x is NaN for x = inf / NaN
 #pragma unroll

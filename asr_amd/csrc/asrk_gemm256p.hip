@@ -443,6 +443,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const GemmArgs a) {
         }
     };
     load_bias(n0);
+#ifdef ASRK_DIAG  // experiment: XCD x starts x * skew * ~1k cycles late, so that the eight XCDs' store bursts do not coincide
+    if (a.skew > 0)
+        for (int i = 0; i < xcd * a.skew; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     PSTAMP(0);
     // prologue: slices 0, 1 and X of slice 2; the order X0 W0 X1 W1 X2 is the order of the stream
     stage_x(0, 0, I0{}); stage_x(0, 0, I1{});
@@ -573,7 +577,13 @@ double schedule_cost(const GemmArgs& a, int mt) {
 }
 
 template <int MT, int EPI, bool OUT_BF16>
-int launch(const GemmArgs& a, hipStream_t st) {
+int launch(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    a.skew = 0;
+#ifdef ASRK_DIAG
+    static const int skew = [] { const char* e = getenv("ASRK_GEMM_PSKEW"); return e ? atoi(e) : 0; }();
+    a.skew = skew;
+#endif
     constexpr int BM = 32 * MT;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per_xcd = ((tiles_m + 7) / 8) * tiles_n;  // tiles of the fullest XCD
