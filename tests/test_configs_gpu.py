@@ -195,3 +195,35 @@ def test_ragged_batch64_collate_encoder_projector(margins):
     with torch.no_grad():
         e1 = encode_and_project(enc, proj, feats[40:41])
     assert rel_l2(emb[40].cpu(), e1[0].cpu()) <= 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ other checkpoint sizes
+# The reference hard-codes openai/whisper-small (src/modeling.py:24) and BASELINE.json adds large-v3; the encoder class
+# takes its dimensions from the checkpoint, so the sizes in between must go through the same kernels' other tile
+# choices (d = 384 is not a multiple of the 256-column tile, 6 / 8 / 16 heads).  Two layers each, three clips.
+@pytest.mark.parametrize("name,d,heads,ffn,n_mels", [("whisper-tiny", 384, 6, 1536, 80), ("whisper-base", 512, 8, 2048, 80),
+                                                      ("whisper-medium", 1024, 16, 4096, 80)])
+def test_other_whisper_sizes_two_layers(name, d, heads, ffn, n_mels, margins):
+    from asr_amd.encoder import WhisperEncoder
+    from asr_amd.projector import encode_and_project
+
+    layers, B, T = 2, 3, 576
+    sd = torch_encoder_state_dict(d, layers, ffn, n_mels, seed=600 + heads)
+    enc = WhisperEncoder.from_state_dict(sd, n_heads=heads)
+    proj, psd = build_projector(d, T, seed=60 + heads)
+    g = torch.Generator().manual_seed(700 + heads)
+    feats = (torch.randn((B, n_mels, 3000), generator=g) * 0.45).clamp_(-1.0, 1.6)
+    h_ref = oracle_encoder.encoder_forward(sd, feats, heads, n_layers=layers)
+    y_ref = oracle_projector.projector_forward(psd, h_ref)
+    with torch.no_grad():
+        h = enc(feats.cuda())
+        y = encode_and_project(enc, proj, feats.cuda())
+    torch.cuda.synchronize()
+    eh, ey = rel_l2(h.cpu(), h_ref), rel_l2(y.float().cpu(), y_ref)
+    print(f"{name} dims x {layers} layers: hidden rel-L2 {eh:.3e}, embeddings rel-L2 {ey:.3e}")
+    margins.add(f"encoder {name} dims, {layers} layers, B={B} vs oracle", eh, REL, "rel-L2")
+    margins.add(f"encoder + projector {name} dims vs oracle chain", ey, REL, "rel-L2")
+    assert eh <= REL and ey <= REL
+    with torch.no_grad():  # a clip's result does not depend on its neighbours beyond bf16 tile-choice noise
+        h1 = enc(feats[1:2].cuda())
+    assert rel_l2(h[1].cpu(), h1[0].cpu()) <= 5e-3
