@@ -172,7 +172,7 @@ int asrk_gemm_launch(const GemmArgs& a, bool gelu, bool out_bf16, hipStream_t st
     constexpr int forced = 0;
 #endif
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const long min_tiles = out_bf16 ? 136 : 512;
+    const long min_tiles = out_bf16 ? 136 : 448;  // fp32: large-v3's conv2 at 16 clips (470 tiles) measured 0.274 vs 0.296 ms on the 128-tile kernel
     // a ragged last n-tile is fine while at least 7/8 of the tiles' columns are real (N = 960: 93.75 %)
     const long n_cover = (long)((a.N + 255) / 256) * 256;
     // the 256-tile kernels have no residual add in their bf16 epilogues (no caller on the path combines the two: the
