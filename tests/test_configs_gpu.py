@@ -227,3 +227,44 @@ def test_other_whisper_sizes_two_layers(name, d, heads, ffn, n_mels, margins):
     with torch.no_grad():  # a clip's result does not depend on its neighbours beyond bf16 tile-choice noise
         h1 = enc(feats[1:2].cuda())
     assert rel_l2(h[1].cpu(), h1[0].cpu()) <= 5e-3
+
+
+def test_the_whole_path_is_capturable_in_a_hip_graph():
+    """Callers that replay the step as a HIP graph (tight serving loops): every entry point only enqueues work on the
+    caller's stream -- no synchronisation, no allocation of its own beyond what the caller's allocator hands it -- so
+    waveform -> log-mel -> encoder -> projector can be captured once and replayed; the replay is bit-identical to
+    stream launches, also after the input buffer has been overwritten in place."""
+    from asr_amd import LogMelFeatureExtractor
+    from asr_amd.encoder import WhisperEncoder
+    from asr_amd.projector import encode_and_project
+
+    d, layers, heads, ffn, n_mels, T, B = 384, 2, 6, 1536, 80, 576, 4
+    enc = WhisperEncoder.from_state_dict(torch_encoder_state_dict(d, layers, ffn, n_mels, seed=808), n_heads=heads)
+    proj, _ = build_projector(d, T, seed=81)
+    fe = LogMelFeatureExtractor(feature_size=n_mels)
+    g = torch.Generator().manual_seed(809)
+    wave = (0.1 * torch.randn((B, 480000), generator=g)).clamp_(-1, 1).cuda()
+    wave2 = (0.1 * torch.randn((B, 480000), generator=g)).clamp_(-1, 1).cuda()
+
+    def step():
+        with torch.no_grad():
+            return encode_and_project(enc, proj, fe.extract_from_device(wave, None))
+
+    eager = step().clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    wave.copy_(wave2)  # new audio in the captured input buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    eager2 = step()
+    assert torch.equal(out, eager2) and not torch.equal(eager2, eager)
